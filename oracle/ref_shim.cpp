@@ -7,7 +7,8 @@
 //   * `private` -> `public`, so the private seams named in SURVEY.md 8(b)
 //     (InnerBnB, ICP, Initialize, OuterBnB, weights, maxRotDis, pDataTemp) can be driven one by one;
 //   * `priority_queue` -> a thin logging wrapper, so every TRANSNODE the reference pushes
-//     ((cube) -> (ub, lb) as computed by jly_goicp.cpp:343-550) can be recorded as a known answer.
+//     ((cube) -> (ub, lb) as computed by jly_goicp.cpp:343-550) can be recorded as a known answer;
+//   * `malloc(n)` -> `calloc(1,n)` for that one translation unit (see the note at the include).
 //
 // Used by: tests/ (oracle pinning), tests/golden/make_golden.py (fixture generation) and
 // bench.py's cpu_baseline leg ("kind": "reference").
@@ -69,7 +70,12 @@ public:
 };
 
 #define priority_queue traced_priority_queue
+// The reference leaves `std::vector` members of malloc'd POINT3D arrays unconstructed and later
+// `delete`s them (jly_goicp.cpp:212-213,271-273), which only works on the zero pages a fresh process
+// gets from malloc. Inside a long-lived test process the heap is dirty, so hand it zeroed blocks.
+#define malloc(n) calloc(1, (n))
 #include "jly_goicp.cpp"   // the reference translation unit itself, unmodified
+#undef malloc
 #undef priority_queue
 #undef private
 

@@ -293,3 +293,179 @@ def error_trace(log):
             tag = line.split("(")[1].split()[0].rstrip(")")
             out.append((tag, v))
     return out
+
+
+class Oracle:
+    """The plain-C restatement (oracle/goicp_oracle.c); same surface as Ref so tests read symmetrically."""
+
+    def __init__(self):
+        self.lib = L = C.CDLL(ORACLE_SO)
+        L.orc_new.restype = C.c_void_p
+        for n in ("orc_inner_bnb", "orc_icp", "orc_register", "orc_sse_thresh", "orc_get_opt_error", "orc_sum_fpfh"):
+            getattr(L, n).restype = C.c_float
+        L.orc_trace_end.restype = C.c_longlong
+        self.h = C.c_void_p(L.orc_new())
+        self.Nd = self.Nm = 0
+
+    def close(self):
+        if self.h:
+            self.lib.orc_free(self.h)
+            self.h = None
+
+    def set_config(self, cfgvec):
+        self.cfgvec = np.ascontiguousarray(cfgvec, dtype=np.float64)
+        self.lib.orc_set_config(self.h, _p(self.cfgvec, C.c_double))
+
+    def set_clouds(self, mxyz, dxyz, mcol=None, dcol=None, mfpfh=None, dfpfh=None):
+        mxyz = np.ascontiguousarray(mxyz, dtype=np.float32); dxyz = np.ascontiguousarray(dxyz, dtype=np.float32)
+        self.Nm, self.Nd = len(mxyz), len(dxyz)
+        f = lambda a, t: None if a is None else np.ascontiguousarray(a, dtype=t)
+        mcol, dcol = f(mcol, np.int32), f(dcol, np.int32)
+        mfpfh, dfpfh = f(mfpfh, np.float32), f(dfpfh, np.float32)
+        self.lib.orc_set_clouds(self.h, self.Nm, _p(mxyz, C.c_float), _p(mcol, C.c_int), _p(mfpfh, C.c_float),
+                                self.Nd, _p(dxyz, C.c_float), _p(dcol, C.c_int), _p(dfpfh, C.c_float))
+
+    def set_nd(self, nd):
+        self.Nd = nd
+        self.lib.orc_set_nd(self.h, nd)
+
+    def _geom(self):
+        g = np.zeros(8)
+        self.lib.orc_dt_geom(self.h, _p(g, C.c_double))
+        self.geom = g
+        self.S = int(g[7])
+
+    def build_dt(self):
+        self.lib.orc_build_dt(self.h)
+        self._geom()
+
+    def load_dt(self, S, geom8, dist, nearest3=None, cellc=None, cell_ptr=None, cell_idx=None):
+        g4 = np.array([geom8[0], geom8[2], geom8[4], geom8[6]], dtype=np.float64)
+        f = lambda a, t: None if a is None else np.ascontiguousarray(a, dtype=t)
+        dist = f(dist, np.float32); nearest3 = f(nearest3, np.int32); cellc = f(cellc, np.int32)
+        cell_ptr = f(cell_ptr, np.int32); cell_idx = f(cell_idx, np.int32)
+        self.lib.orc_load_dt(self.h, int(S), _p(g4, C.c_double), _p(dist, C.c_float), _p(nearest3, C.c_int),
+                             _p(cellc, C.c_int), _p(cell_ptr, C.c_int), _p(cell_idx, C.c_int))
+        self._geom()
+
+    def dt_dump(self, want_vhd=False):
+        S = self.S
+        dist = np.zeros(S ** 3, np.float32); near = np.zeros(S ** 3 * 3, np.int32); cc = np.zeros(S ** 3, np.int32)
+        vhd = np.zeros(S ** 3 * 3, np.int16) if want_vhd else None
+        self.lib.orc_dt_dump(self.h, _p(dist, C.c_float), _p(vhd, C.c_short), _p(near, C.c_int), _p(cc, C.c_int))
+        return dist, near.reshape(-1, 3), cc, (vhd.reshape(-1, 3) if want_vhd else None)
+
+    def cell_points(self, x, y, z):
+        buf = np.zeros(64, np.int32)
+        n = self.lib.orc_cell_points(self.h, x, y, z, _p(buf, C.c_int), 64)
+        return buf[:n].copy()
+
+    def distance(self, q):
+        q = np.ascontiguousarray(q, dtype=np.float64).reshape(-1, 3)
+        out = np.zeros(len(q), np.float32)
+        self.lib.orc_distance(self.h, len(q), _p(q, C.c_double), _p(out, C.c_float))
+        return out
+
+    def initialize(self):
+        self.lib.orc_initialize(self.h)
+
+    def weights(self):
+        w = np.zeros(self.Nd, np.float32); self.lib.orc_get_weights(self.h, _p(w, C.c_float)); return w
+
+    def set_weights(self, w):
+        w = np.ascontiguousarray(w, dtype=np.float32); self.lib.orc_set_weights(self.h, _p(w, C.c_float))
+
+    def maxrotdis(self):
+        m = np.zeros(20 * self.Nd, np.float32); self.lib.orc_get_maxrotdis(self.h, _p(m, C.c_float))
+        return m.reshape(20, self.Nd)
+
+    def inlier_num(self):
+        return self.lib.orc_inlier_num(self.h)
+
+    def sse_thresh(self):
+        return float(self.lib.orc_sse_thresh(self.h))
+
+    def set_sse_thresh(self, v):
+        self.lib.orc_set_sse_thresh(self.h, C.c_float(v))
+
+    def set_opt_error(self, e):
+        self.lib.orc_set_opt_error(self.h, C.c_float(e))
+
+    def set_init_trans(self, x, y, z, w, lb=0.0):
+        self.lib.orc_set_init_trans(self.h, C.c_float(x), C.c_float(y), C.c_float(z), C.c_float(w), C.c_float(lb))
+
+    def set_rotated(self, xyz):
+        xyz = np.ascontiguousarray(xyz, dtype=np.float32)
+        assert xyz.shape[0] == self.Nd
+        self.lib.orc_set_rotated(self.h, _p(xyz, C.c_float))
+
+    def rotate(self, R):
+        R = np.ascontiguousarray(R, dtype=np.float32).reshape(9)
+        self.lib.orc_rotate(self.h, _p(R, C.c_float))
+
+    def eval_cube(self, level, x, y, z, w):
+        ub = C.c_float(); lb = C.c_float()
+        self.lib.orc_eval_cube(self.h, int(level), C.c_float(x), C.c_float(y), C.c_float(z), C.c_float(w),
+                               C.byref(ub), C.byref(lb))
+        return np.float32(ub.value), np.float32(lb.value)
+
+    def eval_cubes(self, level, cubes):
+        cubes = np.asarray(cubes, dtype=np.float32).reshape(-1, 4)
+        out = np.zeros((len(cubes), 2), np.float32)
+        for i, cb in enumerate(cubes):
+            out[i] = self.eval_cube(level, *cb)
+        return out[:, 0].copy(), out[:, 1].copy()
+
+    def inner_bnb(self, level, want_node=True):
+        node = np.zeros(6, np.float32)
+        r = self.lib.orc_inner_bnb(self.h, int(level), _p(node, C.c_float), 1 if want_node else 0)
+        return np.float32(r), node
+
+    def check_compatibilities(self, x, y, z):
+        return int(self.lib.orc_check_compatibilities(self.h, C.c_float(x), C.c_float(y), C.c_float(z)))
+
+    def sum_fpfh(self, x, y, z):
+        return np.float32(self.lib.orc_sum_fpfh(self.h, C.c_float(x), C.c_float(y), C.c_float(z)))
+
+    def icp(self, R, t):
+        R = np.ascontiguousarray(R, dtype=np.float64).reshape(9).copy(); t = np.ascontiguousarray(t, dtype=np.float64).reshape(3).copy()
+        corr = np.zeros(self.Nd * 2, np.int32); dis = np.zeros(self.Nd, np.float64)
+        e = self.lib.orc_icp(self.h, _p(R, C.c_double), _p(t, C.c_double), _p(corr, C.c_int), _p(dis, C.c_double))
+        return np.float32(e), R.reshape(3, 3), t, corr.reshape(-1, 2), dis
+
+    def register(self):
+        out = np.zeros(16, np.float64)
+        self.lib.orc_register(self.h, _p(out, C.c_double))
+        n = self.lib.orc_last_log(self.h, None, 0)
+        buf = C.create_string_buffer(n + 1)
+        self.lib.orc_last_log(self.h, buf, n + 1)
+        return dict(R=out[:9].reshape(3, 3).copy(), t=out[9:12].copy(), error=np.float32(out[12]), comp=int(out[13]),
+                    Nd=int(out[14]), inlierNum=int(out[15]), log=buf.value.decode(errors="replace"))
+
+    def trace_begin(self, cap=1 << 22):
+        self.lib.orc_trace_begin(self.h, C.c_longlong(cap)); self._cap = cap
+
+    def trace_end(self):
+        buf = np.zeros(self._cap * 6, np.float32)
+        n = self.lib.orc_trace_end(self.h, _p(buf, C.c_float), C.c_longlong(self._cap))
+        return buf.reshape(-1, 6)[:min(n, self._cap)].copy()
+
+    def counters(self, reset=True):
+        out = np.zeros(4, np.int64)
+        self.lib.orc_counters(self.h, _p(out, C.c_longlong), 1 if reset else 0)
+        return tuple(int(v) for v in out)
+
+    def intro_select(self, data, k):
+        d = np.ascontiguousarray(data, dtype=np.float32).copy()
+        self.lib.orc_intro_select(_p(d, C.c_float), C.c_longlong(len(d)), C.c_longlong(k))
+        return d
+
+    def svd3_rot(self, H):
+        H = np.ascontiguousarray(H, dtype=np.float64).reshape(9); R = np.zeros(9)
+        self.lib.orc_svd3_rot(_p(H, C.c_double), _p(R, C.c_double))
+        return R.reshape(3, 3)
+
+    def axis_angle(self, v):
+        R = np.zeros(9, np.float32)
+        self.lib.orc_axis_angle(C.c_float(v[0]), C.c_float(v[1]), C.c_float(v[2]), _p(R, C.c_float))
+        return R.reshape(3, 3)
