@@ -1,0 +1,75 @@
+"""Shared test helpers (test infrastructure)."""
+import json
+import os
+
+import numpy as np
+
+from oracle.refbind import Oracle, cfg_vector, CFG_KEYS
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+
+def load_clouds(name):
+    return dict(np.load(os.path.join(GOLDEN, name + "_clouds.npz")))
+
+
+def load_hotpath(name):
+    return dict(np.load(os.path.join(GOLDEN, "hotpath_%s.npz" % name)))
+
+
+def load_register():
+    return json.load(open(os.path.join(GOLDEN, "register.json")))
+
+
+def rot_cloud(R, d):
+    """pDataTemp = R*p in float32, left-to-right, no FMA (jly_goicp.cpp:750-756)."""
+    R = np.asarray(R, np.float32); d = np.asarray(d, np.float32)
+    return np.stack([(R[k, 0] * d[:, 0] + R[k, 1] * d[:, 1]) + R[k, 2] * d[:, 2] for k in range(3)], 1).astype(np.float32)
+
+
+def oracle_for(P, cfgvec, H=None, nd=None):
+    """Oracle context on clouds P with config vector; adopts the fixture's DT tables when H is given."""
+    o = Oracle()
+    o.set_config(cfgvec)
+    o.set_clouds(P["t"], P["s"], P["tc"], P["sc"], P["tf"], P["sf"])
+    if nd:
+        o.set_nd(nd)
+    if H is not None:
+        o.load_dt(int(H["geom"][7]), H["geom"], H["dist"], H["nearest3"], H["cellc"], H["cell_ptr"], H["cell_idx"])
+    else:
+        o.build_dt()
+    return o
+
+
+def synth_pair(n, seed=20260101, noise=0.01, outlier_frac=0.10, tmax=0.2):
+    """SURVEY.md 8(d) synthetic generator: shell cloud on 6 overlapping spheres, centred, max-norm 1,
+    6 significant digits; data = permuted, rotated, translated, noised copy with outliers."""
+    rng = np.random.default_rng(seed)
+    centres = rng.uniform(-0.45, 0.45, (6, 3)); radii = rng.uniform(0.35, 0.6, 6)
+    which = rng.integers(0, 6, n)
+    v = rng.normal(size=(n, 3)); v /= np.linalg.norm(v, axis=1, keepdims=True)
+    m = centres[which] + radii[which, None] * v
+    m -= m.mean(0); m /= np.linalg.norm(m, axis=1).max()
+    m = np.array([[float("%g" % x) for x in row] for row in m])
+    rng2 = np.random.default_rng(seed + 1)
+    aa = rng2.normal(size=3); aa = aa / np.linalg.norm(aa) * rng2.uniform(0.3, np.pi)
+    th = np.linalg.norm(aa); k = aa / th
+    K = np.array([[0, -k[2], k[1]], [k[2], 0, -k[0]], [-k[1], k[0], 0]])
+    Rt = np.eye(3) + np.sin(th) * K + (1 - np.cos(th)) * K @ K
+    tt = rng2.uniform(-tmax, tmax, 3)
+    d = m[rng2.permutation(n)]
+    # data such that  Rt*d + tt ~= model  <=> d = Rt^T (m - tt)
+    d = (d - tt) @ Rt + rng2.normal(scale=noise, size=(n, 3))
+    nout = int(outlier_frac * n)
+    if nout:
+        d[rng2.choice(n, nout, replace=False)] = rng2.uniform(-1, 1, (nout, 3))
+    d = np.array([[float("%g" % x) for x in row] for row in d])
+    props = np.array([8204959, 30894, 15219528, 15231913, 4646984, 16741671, 7566712, 0], np.int32)
+    mc = props[rng.integers(0, 8, n)]; dc = props[rng2.integers(0, 8, n)]
+
+    def fp(r, k):
+        a = r.uniform(0, 1, (k, 33)); a = a / a.sum(1, keepdims=True) * 600
+        b = r.uniform(0, 1, (k, 8)); b = b / b.sum(1, keepdims=True) * 200
+        return np.concatenate([a, b], 1).astype(np.float32)
+    return dict(t=m.astype(np.float32), s=d.astype(np.float32), tc=mc, sc=dc, tf=fp(rng, n), sf=fp(rng2, n), Rtrue=Rt, ttrue=tt)
