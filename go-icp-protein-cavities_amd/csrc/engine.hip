@@ -1,0 +1,936 @@
+// engine.hip -- MI355X (gfx950 / CDNA4) Go-ICP inner-BnB error-evaluation engine.
+//
+// Hand-written HIP kernels for the hot path named in BASELINE.json:north_star; C ABI in
+// include/goicp_engine.h (which cites the reference seam each entry point replaces).
+// Compile with -ffp-contract=off: the reference arithmetic has no FMA (SURVEY.md 8(a')).
+//
+// Kernels
+//   k_inner_bnb   one workgroup = one whole InnerBnB call (reference jly_goicp.cpp:286-579): the data
+//                 cloud is rotated in-kernel and lives in registers (PPT points per lane), each queue pop
+//                 sweeps the 8 child cubes (8*Nd DT gathers), selects the inliers with an LDS radix select,
+//                 evaluates the 27 shared corner-lattice penalty terms, and lane 0 replays the reference's
+//                 prune/push decisions on a binary heap that reproduces std::priority_queue's order.
+//   k_eval_cubes  the same sweep for an arbitrary list of cubes (8 cubes per workgroup), for callers that
+//                 drive the queue themselves and for the cube-evals/s benchmark.
+//   k_rotate, k_corner_terms, k_point_eval, k_icp_nn   small helpers (see goicp_engine.h).
+//
+// Data layout in HBM (staged once per engine): DT distance grid float[S^3] x-fastest; compat mask
+// uint16[S^3] (bit c set <=> a data point of colour class c is compatible with the nearest occupied cell of
+// that cell -- jly_goicp.cpp:974-1000,1068-1092 folded into one gather); nearest-occupied compact id
+// int32[S^3] + CSR of model points per occupied cell + c-FPFH rows (only when regularizationFPFH>0).
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+#include <math.h>
+#include <string>
+#include <vector>
+#include <map>
+#include <algorithm>
+
+#include "goicp_engine.h"
+
+#define TC 8            // cubes per workgroup tile (the 8 children of one queue pop)
+#define NLMAX 64        // lattice points per tile: 27 (shared child corners) or 8*TC (free cubes)
+#define SQRT3_D 1.732050808   // jly_goicp.h:45
+
+struct DevTables {
+    int S;
+    double xMin, yMin, zMin, scale;
+    const float* dist;
+    const uint16_t* cmask;
+    const int* occ;          // [S^3] compact id of the nearest occupied cell, -1 if none
+    const int* occ_ptr;      // [nOcc+1]
+    const int* occ_pts;      // model ids
+    const float* mfpfh;      // [Nm*41]
+    const float* dfpfh;      // [Nd*41]
+    const float* dxyz;       // [Nd*3]
+    const uint8_t* dcls;     // [Nd] colour class of each data point
+    const float* weights;    // [Nd]
+    const float* maxRotDis;  // [20*Nd]
+    int Nd, Nm, inlierNum, doTrim, norm, b0, b1;
+    float reg, regFPFH;
+    int use_compat, use_fpfh, exact;
+};
+
+struct HeapNode { float x, y, z, w, ub, lb; };
+
+// ---------------------------------------------------------------------------------------------
+// device helpers
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ int cell_of(float v, double mn, double scale) {
+    // ROUND((x - xMin) * scale), reference jly_3ddt.cpp:30,1142-1144: double math, truncation toward zero
+    return (int)(((double)v - mn) * scale + 0.5);
+}
+
+// DT3D::Distance (reference jly_3ddt.cpp:1139-1191): one nearest-cell read; out-of-grid extension
+__device__ __forceinline__ float dt_lookup(const DevTables& T, float X, float Y, float Z) {
+    const int S = T.S;
+    int x = cell_of(X, T.xMin, T.scale), y = cell_of(Y, T.yMin, T.scale), z = cell_of(Z, T.zMin, T.scale);
+    if ((unsigned)x < (unsigned)S && (unsigned)y < (unsigned)S && (unsigned)z < (unsigned)S)
+        return T.dist[((size_t)z * S + y) * S + x];
+    float a = 0.f, b = 0.f, c = 0.f;
+    if (x < 0) { a = (float)x; x = 0; } else if (x >= S) { a = (float)(x - S + 1); x = S - 1; }
+    if (y < 0) { b = (float)y; y = 0; } else if (y >= S) { b = (float)(y - S + 1); y = S - 1; }
+    if (z < 0) { c = (float)z; z = 0; } else if (z >= S) { c = (float)(z - S + 1); z = S - 1; }
+    float r = sqrtf(a * a + b * b + c * c);
+    return (float)((double)r / T.scale + (double)T.dist[((size_t)z * S + y) * S + x]);
+}
+
+__device__ __forceinline__ size_t clamped_cell(const DevTables& T, float X, float Y, float Z) {
+    // checkCompatibility / computeFPFHDifference prologue (reference jly_goicp.cpp:974-985, 1642-1651)
+    const int S = T.S;
+    int x = cell_of(X, T.xMin, T.scale), y = cell_of(Y, T.yMin, T.scale), z = cell_of(Z, T.zMin, T.scale);
+    x = x < 0 ? 0 : (x >= S ? S - 1 : x);
+    y = y < 0 ? 0 : (y >= S ? S - 1 : y);
+    z = z < 0 ? 0 : (z >= S ? S - 1 : z);
+    return ((size_t)z * S + y) * S + x;
+}
+
+// min over the model points of the nearest occupied cell of the L1 distance between c-FPFH rows
+// (computeFPFHDifference(false,...), reference jly_goicp.cpp:1642-1681)
+__device__ __forceinline__ float fpfh_min(const DevTables& T, int i, float X, float Y, float Z) {
+    int o = T.occ[clamped_cell(T, X, Y, Z)];
+    float minD = 1000000000.f;
+    if (o < 0) return minD;
+    const float* f = T.dfpfh + (size_t)GOICP_FPFH_BINS * i;
+    for (int p = T.occ_ptr[o]; p < T.occ_ptr[o + 1]; p++) {
+        const float* g = T.mfpfh + (size_t)GOICP_FPFH_BINS * T.occ_pts[p];
+        float diff = 0.f;
+        for (int b = T.b0; b < T.b1; b++) diff += fabsf(f[b] - g[b]);
+        if (diff < minD) minD = diff;
+    }
+    return minD;
+}
+
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+    return v;
+}
+
+template <int BLOCK>
+struct TileShm {
+    float cube[TC][4];        // x, y, z, w
+    float cen[TC][3];         // centre translation
+    float mtd[TC];            // maxTransDis
+    unsigned hist[TC][256];
+    unsigned prefix[TC];
+    int rem[TC];
+    double red[BLOCK / 64][2 * TC];
+    float ub[TC], lb[TC];
+    float lat[NLMAX][3];
+    int cnt[NLMAX];
+    float fpv[NLMAX];
+    int ctl[4];               // [0] done flag, [1] status
+};
+
+// Evaluate the TC cubes whose descriptors sit in sh.cube[] against the PPT points each lane holds in
+// registers. Results: sh.ub[], sh.lb[] (geometric part only; the penalty part is added by the caller).
+// Restates reference jly_goicp.cpp:343-415.
+template <int BLOCK, int PPT>
+__device__ __forceinline__ void sweep_tile(const DevTables& T, TileShm<BLOCK>& sh, const float (&px)[PPT], const float (&py)[PPT],
+                                           const float (&pz)[PPT], const float (&pw)[PPT], const float (&prho)[PPT], bool use_rho,
+                                           float* rbuf /* LDS, exact mode only */) {
+    const int tid = threadIdx.x;
+    const int Nd = T.Nd;
+    float r[TC][PPT];
+#pragma unroll
+    for (int m = 0; m < PPT; m++) {
+        const int i = tid + m * BLOCK;
+        const bool valid = i < Nd;
+#pragma unroll
+        for (int j = 0; j < TC; j++) {
+            float d = 0.f;
+            if (valid) {
+                d = pw[m] * dt_lookup(T, px[m] + sh.cen[j][0], py[m] + sh.cen[j][1], pz[m] + sh.cen[j][2]);
+                if (use_rho) d -= prho[m];
+                if (d < 0.f) d = 0.f;
+            }
+            r[j][m] = d;
+        }
+    }
+    if (T.exact && !T.doTrim) {
+        // reference order: float, sequential over the point index (bit-exact with jly_goicp.cpp:393-415)
+#pragma unroll
+        for (int m = 0; m < PPT; m++) {
+            const int i = tid + m * BLOCK;
+            if (i < Nd) {
+#pragma unroll
+                for (int j = 0; j < TC; j++) rbuf[j * Nd + i] = r[j][m];
+            }
+        }
+        __syncthreads();
+        if (tid < TC) {
+            const float* rr = rbuf + tid * Nd;
+            const float mtd = sh.mtd[tid];
+            float ub = 0.f, lb = 0.f;
+            if (T.norm == 2) {
+                for (int i = 0; i < Nd; i++) { float d = rr[i]; ub += d * d; float e = d - mtd; if (e > 0.f) lb += e * e; }
+            } else if (T.norm == 1) {
+                for (int i = 0; i < Nd; i++) { float d = rr[i]; ub += d; float e = d - mtd; if (e > 0.f) lb += e; }
+            }
+            sh.ub[tid] = ub; sh.lb[tid] = lb;
+        }
+        __syncthreads();
+        return;
+    }
+    // ---- inlier threshold per cube: k-th smallest residual by 4x8-bit radix select on the float bits
+    //      (residuals are >= 0, so the bit pattern orders like the value). Replaces intro_select
+    //      (reference jly_sorting.hpp:229): the selected multiset is identical, the order is not needed.
+    if (T.doTrim) {
+        if (tid < TC) { sh.prefix[tid] = 0u; sh.rem[tid] = T.inlierNum - 1; }
+        for (int pass = 3; pass >= 0; pass--) {
+            for (int k = tid; k < TC * 256; k += BLOCK) (&sh.hist[0][0])[k] = 0u;
+            __syncthreads();
+            const unsigned himask = pass == 3 ? 0u : (0xFFFFFFFFu << (8 * (pass + 1)));
+#pragma unroll
+            for (int m = 0; m < PPT; m++) {
+                if (tid + m * BLOCK < Nd) {
+#pragma unroll
+                    for (int j = 0; j < TC; j++) {
+                        unsigned bits = __float_as_uint(r[j][m]);
+                        if (((bits ^ sh.prefix[j]) & himask) == 0u) atomicAdd(&sh.hist[j][(bits >> (8 * pass)) & 255u], 1u);
+                    }
+                }
+            }
+            __syncthreads();
+            if (tid < TC) {
+                int rem = sh.rem[tid];
+                unsigned dgt = 0;
+                for (; dgt < 255u; dgt++) { int h = (int)sh.hist[tid][dgt]; if (rem < h) break; rem -= h; }
+                sh.prefix[tid] |= dgt << (8 * pass);
+                sh.rem[tid] = rem;
+            }
+            __syncthreads();
+        }
+    }
+    // ---- sums in fp64 (order-free), float at the end; one cube at a time to keep registers low
+    const int wave = tid >> 6, lane = tid & 63;
+#pragma unroll
+    for (int j = 0; j < TC; j++) {
+        double aub = 0.0, alb = 0.0;
+        const float mtd = sh.mtd[j];
+        const unsigned thr = sh.prefix[j];
+#pragma unroll
+        for (int m = 0; m < PPT; m++) {
+            if (tid + m * BLOCK < Nd) {
+                const float d = r[j][m];
+                const bool in = !T.doTrim || __float_as_uint(d) < thr;
+                if (in) {
+                    const float e = d - mtd;
+                    if (T.norm == 2) { aub += (double)(d * d); if (e > 0.f) alb += (double)(e * e); }
+                    else if (T.norm == 1) { aub += (double)d; if (e > 0.f) alb += (double)e; }
+                }
+            }
+        }
+        const double u = wave_sum(aub), l = wave_sum(alb);
+        if (lane == 0) { sh.red[wave][2 * j] = u; sh.red[wave][2 * j + 1] = l; }
+    }
+    __syncthreads();
+    if (tid < TC) {
+        double u = 0.0, l = 0.0;
+        for (int w = 0; w < BLOCK / 64; w++) { u += sh.red[w][2 * tid]; l += sh.red[w][2 * tid + 1]; }
+        if (T.doTrim) {
+            // the (rem+1) copies of the threshold value that belong to the inlier set
+            float d = __uint_as_float(sh.prefix[tid]);
+            float e = d - sh.mtd[tid];
+            double n = (double)(sh.rem[tid] + 1);
+            if (T.norm == 2) { u += n * (double)(d * d); if (e > 0.f) l += n * (double)(e * e); }
+            else if (T.norm == 1) { u += n * (double)d; if (e > 0.f) l += n * (double)e; }
+        }
+        sh.ub[tid] = (float)u; sh.lb[tid] = (float)l;
+    }
+    __syncthreads();
+}
+
+// Penalty terms at the nl translations in sh.lat[]: incompatibility counts (checkCompatibilities, reference
+// jly_goicp.cpp:919-928) into sh.cnt[], c-FPFH means (sumFPFH, jly_goicp.cpp:1689-1697) into sh.fpv[].
+template <int BLOCK, int PPT>
+__device__ __forceinline__ void lattice_terms(const DevTables& T, TileShm<BLOCK>& sh, int nl, const float (&px)[PPT], const float (&py)[PPT],
+                                              const float (&pz)[PPT], float* fpbuf /* global scratch [NLMAX*Nd] */) {
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int Nd = T.Nd;
+    if (T.use_compat) {
+        for (int l = tid; l < nl; l += BLOCK) sh.cnt[l] = 0;
+        __syncthreads();
+        unsigned cls[PPT];
+#pragma unroll
+        for (int m = 0; m < PPT; m++) cls[m] = (tid + m * BLOCK < Nd) ? (unsigned)T.dcls[tid + m * BLOCK] : 0u;
+        for (int l = 0; l < nl; l++) {
+            const float lx = sh.lat[l][0], ly = sh.lat[l][1], lz = sh.lat[l][2];
+            int wave_cnt = 0;
+#pragma unroll
+            for (int m = 0; m < PPT; m++) {
+                bool bad = false;
+                if (tid + m * BLOCK < Nd) {
+                    unsigned mask = T.cmask[clamped_cell(T, px[m] + lx, py[m] + ly, pz[m] + lz)];
+                    bad = ((mask >> cls[m]) & 1u) == 0u;
+                }
+                wave_cnt += __popcll(__ballot(bad));
+            }
+            if (lane == 0 && wave_cnt) atomicAdd(&sh.cnt[l], wave_cnt);
+        }
+        __syncthreads();
+    }
+    if (T.use_fpfh) {
+        for (int l = 0; l < nl; l++) {
+            const float lx = sh.lat[l][0], ly = sh.lat[l][1], lz = sh.lat[l][2];
+#pragma unroll
+            for (int m = 0; m < PPT; m++) {
+                const int i = tid + m * BLOCK;
+                if (i < Nd) fpbuf[(size_t)l * Nd + i] = fpfh_min(T, i, px[m] + lx, py[m] + ly, pz[m] + lz);
+            }
+        }
+        __syncthreads();
+        // the mean is truncated to int by the caller (reference jly_goicp.cpp:468,495), so the float sum must
+        // round exactly like the reference's: sequential over the point index
+        for (int l = tid; l < nl; l += BLOCK) {
+            const float* f = fpbuf + (size_t)l * Nd;
+            float s = 0.f;
+            for (int i = 0; i < Nd; i++) s += f[i];
+            sh.fpv[l] = s / (float)Nd;
+        }
+        __syncthreads();
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// binary heap with the element order of std::priority_queue<TRANSNODE> (reference jly_goicp.h:75-87):
+// the hole is sifted to a leaf along the not-lower child, then the displaced value is sifted up.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ bool node_lower(const HeapNode& p, const HeapNode& q) { return p.lb != q.lb ? p.lb > q.lb : p.w < q.w; }
+
+__device__ __forceinline__ void heap_up(HeapNode* a, int hole, const HeapNode& v) {
+    int par = (hole - 1) / 2;
+    while (hole > 0 && node_lower(a[par], v)) { a[hole] = a[par]; hole = par; par = (hole - 1) / 2; }
+    a[hole] = v;
+}
+__device__ __forceinline__ void heap_pop(HeapNode* a, int& n) {
+    if (n > 1) {
+        const int len = n - 1;
+        HeapNode v = a[len];
+        a[len] = a[0];
+        int hole = 0, child = 0;
+        while (child < (len - 1) / 2) {
+            child = 2 * (child + 1);
+            if (node_lower(a[child], a[child - 1])) child--;
+            a[hole] = a[child]; hole = child;
+        }
+        if ((len & 1) == 0 && child == (len - 2) / 2) { child = 2 * (child + 1); a[hole] = a[child - 1]; hole = child - 1; }
+        heap_up(a, hole, v);
+    }
+    n--;
+}
+
+// ---------------------------------------------------------------------------------------------
+// k_inner_bnb
+// ---------------------------------------------------------------------------------------------
+template <int BLOCK, int PPT>
+__global__ __launch_bounds__(BLOCK) void k_inner_bnb(DevTables T, const goicp_bnb_job* __restrict__ jobs, goicp_bnb_result* __restrict__ results,
+                                                      HeapNode* heaps, int heap_cap, float* fpscratch, unsigned max_pops) {
+    __shared__ TileShm<BLOCK> sh;
+    __shared__ HeapNode parent;
+    extern __shared__ float rbuf[];
+    const int tid = threadIdx.x;
+    const int Nd = T.Nd;
+    const goicp_bnb_job job = jobs[blockIdx.x];
+    HeapNode* heap = heaps + (size_t)blockIdx.x * heap_cap;
+    float* fpbuf = fpscratch ? fpscratch + (size_t)blockIdx.x * NLMAX * Nd : nullptr;
+
+    // K5 fused: pDataTemp = R*p, float, left to right (reference jly_goicp.cpp:750-756)
+    float px[PPT], py[PPT], pz[PPT], pw[PPT], prho[PPT];
+    const bool use_rho = job.rot_level >= 0;
+#pragma unroll
+    for (int m = 0; m < PPT; m++) {
+        const int i = tid + m * BLOCK;
+        px[m] = py[m] = pz[m] = 0.f; pw[m] = 0.f; prho[m] = 0.f;
+        if (i < Nd) {
+            const float x = T.dxyz[3 * i], y = T.dxyz[3 * i + 1], z = T.dxyz[3 * i + 2];
+            px[m] = job.R[0] * x + job.R[1] * y + job.R[2] * z;
+            py[m] = job.R[3] * x + job.R[4] * y + job.R[5] * z;
+            pz[m] = job.R[6] * x + job.R[7] * y + job.R[8] * z;
+            pw[m] = T.weights[i];
+            if (use_rho) prho[m] = T.maxRotDis[(size_t)job.rot_level * Nd + i];
+        }
+    }
+
+    // lane-0 state
+    float optErrorT = job.optError_in;
+    float bx = 0.f, by = 0.f, bz = 0.f, bw = 0.f;
+    int found = 0, hn = 0, status = GOICP_OK;
+    unsigned pops = 0, cubes = 0;
+    if (tid == 0) {
+        HeapNode root; root.x = job.init[0]; root.y = job.init[1]; root.z = job.init[2]; root.w = job.init[3]; root.ub = 0.f; root.lb = job.init_lb;
+        heap[0] = root; hn = 1;
+    }
+    const bool penalties = T.use_compat || T.use_fpfh;
+
+    for (;;) {
+        if (tid == 0) {
+            int done = 0;
+            if (hn == 0) done = 1;
+            else {
+                parent = heap[0];
+                heap_pop(heap, hn);
+                pops++;
+                if (optErrorT - parent.lb < job.SSEThresh) done = 1;          // reference jly_goicp.cpp:317
+                else if (pops > max_pops) { done = 1; status = GOICP_ERR_LIMIT; }
+                else if (hn + 8 > heap_cap) { done = 1; status = GOICP_ERR_OVERFLOW; }
+            }
+            sh.ctl[0] = done;
+        }
+        __syncthreads();
+        if (sh.ctl[0]) break;
+        // children (reference jly_goicp.cpp:322-333) and the 3x3x3 lattice of their corners (:436-437,486-488)
+        if (tid < TC) {
+            const int j = tid;
+            const float w = parent.w / 2;
+            const float x = parent.x + (j & 1) * w, y = parent.y + (j >> 1 & 1) * w, z = parent.z + (j >> 2 & 1) * w;
+            sh.cube[j][0] = x; sh.cube[j][1] = y; sh.cube[j][2] = z; sh.cube[j][3] = w;
+            sh.cen[j][0] = x + w / 2; sh.cen[j][1] = y + w / 2; sh.cen[j][2] = z + w / 2;
+            sh.mtd[j] = (float)(SQRT3_D / 2.0 * w);
+        }
+        if (penalties && tid >= 64 && tid < 64 + 27) {
+            const int l = tid - 64, ax = l % 3, ay = (l / 3) % 3, az = l / 9;
+            const float w = parent.w / 2;
+            // coordinate k of the lattice along one axis: p, p+w, (p+w)+w  == child origin + corner offset
+            const float x1 = parent.x + w, y1 = parent.y + w, z1 = parent.z + w;
+            sh.lat[l][0] = ax == 0 ? parent.x : (ax == 1 ? x1 : x1 + w);
+            sh.lat[l][1] = ay == 0 ? parent.y : (ay == 1 ? y1 : y1 + w);
+            sh.lat[l][2] = az == 0 ? parent.z : (az == 1 ? z1 : z1 + w);
+        }
+        __syncthreads();
+        sweep_tile<BLOCK, PPT>(T, sh, px, py, pz, pw, prho, use_rho, rbuf);
+        if (penalties) lattice_terms<BLOCK, PPT>(T, sh, 27, px, py, pz, fpbuf);
+        if (tid == 0) {
+            cubes += 8;
+            for (int j = 0; j < TC; j++) {
+                float ub = sh.ub[j], lb = sh.lb[j];
+                if (penalties) {
+                    // extremes over the cube's 8 corners (reference jly_goicp.cpp:431-549)
+                    int minI = 0, maxI = 0; float minF = 0.f, maxF = 0.f;
+                    for (int c = 0; c < 8; c++) {
+                        const int l = ((j >> 2 & 1) + (c >> 2 & 1)) * 9 + ((j >> 1 & 1) + (c >> 1 & 1)) * 3 + ((j & 1) + (c & 1));
+                        if (T.use_compat) { int v = sh.cnt[l]; if (c == 0) { minI = maxI = v; } else { if (v > maxI) maxI = v; if (v < minI) minI = v; } }
+                        if (T.use_fpfh) { int v = (int)sh.fpv[l]; if (c == 0) { minF = maxF = (float)v; } else { if (v > maxF) maxF = (float)v; if (v < minF) minF = (float)v; } }
+                    }
+                    if (T.use_compat) { ub += T.reg * (float)(maxI * maxI); lb += T.reg * (float)(minI * minI); }
+                    if (T.use_fpfh) { ub += T.regFPFH * (maxF * maxF); lb += T.regFPFH * (minF * minF); }
+                }
+                if (ub < optErrorT) { optErrorT = ub; bx = sh.cube[j][0]; by = sh.cube[j][1]; bz = sh.cube[j][2]; bw = sh.cube[j][3]; found = 1; }
+                if (lb >= optErrorT) continue;                                  // reference jly_goicp.cpp:568
+                HeapNode nd; nd.x = sh.cube[j][0]; nd.y = sh.cube[j][1]; nd.z = sh.cube[j][2]; nd.w = sh.cube[j][3]; nd.ub = ub; nd.lb = lb;
+                hn++;
+                heap_up(heap, hn - 1, nd);
+            }
+        }
+        // (the barrier at the top of the next iteration orders lane 0's heap work before anyone reads `parent`)
+    }
+    if (tid == 0) {
+        goicp_bnb_result r;
+        r.optErrorT = optErrorT; r.node[0] = bx; r.node[1] = by; r.node[2] = bz; r.node[3] = bw;
+        r.found = found; r.status = status; r.pops = pops; r.cube_evals = cubes;
+        results[blockIdx.x] = r;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// k_eval_cubes: 8 free cubes per workgroup; cloud = rotation slot prepared by k_rotate
+// ---------------------------------------------------------------------------------------------
+template <int BLOCK, int PPT>
+__global__ __launch_bounds__(BLOCK) void k_eval_cubes(DevTables T, const float4* __restrict__ rot /*[Nd] x,y,z,weight*/, int rot_level,
+                                                       const float* __restrict__ cubes, int n, float* __restrict__ ub_out, float* __restrict__ lb_out,
+                                                       float* fpscratch) {
+    __shared__ TileShm<BLOCK> sh;
+    extern __shared__ float rbuf[];
+    const int tid = threadIdx.x;
+    const int Nd = T.Nd;
+    const int base = blockIdx.x * TC;
+    float* fpbuf = fpscratch ? fpscratch + (size_t)blockIdx.x * NLMAX * Nd : nullptr;
+    float px[PPT], py[PPT], pz[PPT], pw[PPT], prho[PPT];
+    const bool use_rho = rot_level >= 0;
+#pragma unroll
+    for (int m = 0; m < PPT; m++) {
+        const int i = tid + m * BLOCK;
+        px[m] = py[m] = pz[m] = 0.f; pw[m] = 0.f; prho[m] = 0.f;
+        if (i < Nd) {
+            float4 p = rot[i];
+            px[m] = p.x; py[m] = p.y; pz[m] = p.z; pw[m] = p.w;
+            if (use_rho) prho[m] = T.maxRotDis[(size_t)rot_level * Nd + i];
+        }
+    }
+    if (tid < TC) {
+        const int j = tid, c = min(base + j, n - 1);          // the tail tile re-evaluates the last cube
+        const float x = cubes[4 * c], y = cubes[4 * c + 1], z = cubes[4 * c + 2], w = cubes[4 * c + 3];
+        sh.cube[j][0] = x; sh.cube[j][1] = y; sh.cube[j][2] = z; sh.cube[j][3] = w;
+        sh.cen[j][0] = x + w / 2; sh.cen[j][1] = y + w / 2; sh.cen[j][2] = z + w / 2;
+        sh.mtd[j] = (float)(SQRT3_D / 2.0 * w);
+    }
+    const bool penalties = T.use_compat || T.use_fpfh;
+    __syncthreads();
+    if (penalties && tid < 8 * TC) {
+        const int j = tid >> 3, c = tid & 7;
+        sh.lat[tid][0] = sh.cube[j][0] + (c & 1) * sh.cube[j][3];
+        sh.lat[tid][1] = sh.cube[j][1] + (c >> 1 & 1) * sh.cube[j][3];
+        sh.lat[tid][2] = sh.cube[j][2] + (c >> 2 & 1) * sh.cube[j][3];
+    }
+    __syncthreads();
+    sweep_tile<BLOCK, PPT>(T, sh, px, py, pz, pw, prho, use_rho, rbuf);
+    if (penalties) lattice_terms<BLOCK, PPT>(T, sh, 8 * TC, px, py, pz, fpbuf);
+    if (tid < TC && base + tid < n) {
+        const int j = tid;
+        float ub = sh.ub[j], lb = sh.lb[j];
+        if (penalties) {
+            int minI = 0, maxI = 0; float minF = 0.f, maxF = 0.f;
+            for (int c = 0; c < 8; c++) {
+                const int l = j * 8 + c;
+                if (T.use_compat) { int v = sh.cnt[l]; if (c == 0) { minI = maxI = v; } else { if (v > maxI) maxI = v; if (v < minI) minI = v; } }
+                if (T.use_fpfh) { int v = (int)sh.fpv[l]; if (c == 0) { minF = maxF = (float)v; } else { if (v > maxF) maxF = (float)v; if (v < minF) minF = (float)v; } }
+            }
+            if (T.use_compat) { ub += T.reg * (float)(maxI * maxI); lb += T.reg * (float)(minI * minI); }
+            if (T.use_fpfh) { ub += T.regFPFH * (maxF * maxF); lb += T.regFPFH * (minF * minF); }
+        }
+        ub_out[base + j] = ub; lb_out[base + j] = lb;
+    }
+}
+
+// lattice terms only, at n free translations (NLMAX per workgroup)
+template <int BLOCK, int PPT>
+__global__ __launch_bounds__(BLOCK) void k_corner_terms(DevTables T, const float4* __restrict__ rot, const float* __restrict__ xyz, int n,
+                                                         int* __restrict__ cnt_out, float* __restrict__ fp_out, float* fpscratch) {
+    __shared__ TileShm<BLOCK> sh;
+    const int tid = threadIdx.x, Nd = T.Nd, base = blockIdx.x * NLMAX;
+    const int nl = min(NLMAX, n - base);
+    float* fpbuf = fpscratch ? fpscratch + (size_t)blockIdx.x * NLMAX * Nd : nullptr;
+    float px[PPT], py[PPT], pz[PPT];
+#pragma unroll
+    for (int m = 0; m < PPT; m++) {
+        const int i = tid + m * BLOCK;
+        px[m] = py[m] = pz[m] = 0.f;
+        if (i < Nd) { float4 p = rot[i]; px[m] = p.x; py[m] = p.y; pz[m] = p.z; }
+    }
+    for (int l = tid; l < nl; l += BLOCK) { sh.lat[l][0] = xyz[3 * (base + l)]; sh.lat[l][1] = xyz[3 * (base + l) + 1]; sh.lat[l][2] = xyz[3 * (base + l) + 2]; sh.cnt[l] = 0; sh.fpv[l] = 0.f; }
+    __syncthreads();
+    lattice_terms<BLOCK, PPT>(T, sh, nl, px, py, pz, fpbuf);
+    for (int l = tid; l < nl; l += BLOCK) { cnt_out[base + l] = T.use_compat ? sh.cnt[l] : 0; fp_out[base + l] = T.use_fpfh ? sh.fpv[l] : 0.f; }
+}
+
+// K5: rotated cloud + weight as float4 (reference jly_goicp.cpp:750-756)
+__global__ void k_rotate(DevTables T, const float* __restrict__ R, float4* __restrict__ out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= T.Nd) return;
+    const float x = T.dxyz[3 * i], y = T.dxyz[3 * i + 1], z = T.dxyz[3 * i + 2];
+    float4 p;
+    p.x = R[0] * x + R[1] * y + R[2] * z;
+    p.y = R[3] * x + R[4] * y + R[5] * z;
+    p.z = R[6] * x + R[7] * y + R[8] * z;
+    p.w = T.weights[i];
+    out[i] = p;
+}
+
+// (float)(R*p + t) with double R,t (reference jly_goicp.cpp:120-122, 937-939), DT lookup, compat flag
+__global__ void k_point_eval(DevTables T, const double* __restrict__ Rt /*R[9], t[3]*/, float* __restrict__ dist, int* __restrict__ compat) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= T.Nd) return;
+    const float px = T.dxyz[3 * i], py = T.dxyz[3 * i + 1], pz = T.dxyz[3 * i + 2];
+    const float x = (float)(Rt[0] * px + Rt[1] * py + Rt[2] * pz + Rt[9]);
+    const float y = (float)(Rt[3] * px + Rt[4] * py + Rt[5] * pz + Rt[10]);
+    const float z = (float)(Rt[6] * px + Rt[7] * py + Rt[8] * pz + Rt[11]);
+    dist[i] = dt_lookup(T, x, y, z);
+    if (compat) {
+        int ok = 1;
+        if (T.cmask) { unsigned mask = T.cmask[clamped_cell(T, x, y, z)]; ok = (mask >> T.dcls[i]) & 1u; }
+        compat[i] = ok;
+    }
+}
+
+// exhaustive 1-NN in float with the distance expression of the reference's kd-tree metric
+// (jly_icp3d.hpp:54-60); strict '<' keeps the lowest model index among exact ties.
+#define NN_TILE 1024
+__global__ __launch_bounds__(256) void k_icp_nn(DevTables T, const float* __restrict__ mxyz, const float* __restrict__ Rt /*float R[9], t[3]*/,
+                                                 int* __restrict__ id_out, float* __restrict__ d_out) {
+    __shared__ float sm[NN_TILE * 3];
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    float q0 = 0.f, q1 = 0.f, q2 = 0.f;
+    if (i < T.Nd) {
+        const float d0 = T.dxyz[3 * i], d1 = T.dxyz[3 * i + 1], d2 = T.dxyz[3 * i + 2];
+        q0 = Rt[0] * d0 + Rt[1] * d1 + Rt[2] * d2 + Rt[9];
+        q1 = Rt[3] * d0 + Rt[4] * d1 + Rt[5] * d2 + Rt[10];
+        q2 = Rt[6] * d0 + Rt[7] * d1 + Rt[8] * d2 + Rt[11];
+    }
+    float best = INFINITY; int bi = 0;
+    for (int base = 0; base < T.Nm; base += NN_TILE) {
+        const int cnt = min(NN_TILE, T.Nm - base);
+        __syncthreads();
+        for (int k = threadIdx.x; k < cnt * 3; k += blockDim.x) sm[k] = mxyz[(size_t)base * 3 + k];
+        __syncthreads();
+        for (int m = 0; m < cnt; m++) {
+            const float e0 = q0 - sm[3 * m], e1 = q1 - sm[3 * m + 1], e2 = q2 - sm[3 * m + 2];
+            const float d = e0 * e0 + e1 * e1 + e2 * e2;
+            if (d < best) { best = d; bi = base + m; }
+        }
+    }
+    if (i < T.Nd) { id_out[i] = bi; d_out[i] = best; }
+}
+
+// ---------------------------------------------------------------------------------------------
+// host side
+// ---------------------------------------------------------------------------------------------
+struct goicp_engine {
+    int device;
+    hipStream_t stream;
+    hipEvent_t ev0, ev1;
+    DevTables T;
+    std::vector<void*> allocs;
+    // device buffers
+    float* d_mxyz; float4* d_rot; float* d_R; int nslots;
+    goicp_bnb_job* d_jobs; goicp_bnb_result* d_results; int job_cap;
+    HeapNode* d_heaps; int heap_cap; size_t heap_jobs;
+    float* d_fpscratch; size_t fp_blocks;
+    float* d_cubes; float* d_ub; float* d_lb; int cube_cap;
+    double* d_Rt; float* d_Rtf; float* d_dist; int* d_int; float* d_lat; int lat_cap; int* d_cnt; float* d_fp;
+    int block, ppt; size_t dyn_lds;
+    unsigned max_pops;
+    uint64_t n_cubes, n_lookups; double kernel_ms;
+    std::string err;
+};
+
+static int fail(goicp_engine* h, int code, const std::string& msg) { if (h) h->err = msg; return code; }
+#define HIPCHK(h, call) do { hipError_t e_ = (call); if (e_ != hipSuccess) return fail(h, GOICP_ERR_HIP, std::string(#call) + ": " + hipGetErrorString(e_)); } while (0)
+
+template <class Tp>
+static int dev_upload(goicp_engine* h, const Tp* src, size_t n, Tp** out) {
+    Tp* p = nullptr;
+    HIPCHK(h, hipMalloc((void**)&p, std::max<size_t>(n, 1) * sizeof(Tp)));
+    h->allocs.push_back(p);
+    if (src && n) HIPCHK(h, hipMemcpy(p, src, n * sizeof(Tp), hipMemcpyHostToDevice));
+    *out = p;
+    return GOICP_OK;
+}
+
+static bool known_prop(int c) {   // keys of the identity compatibility map, reference jly_goicp.cpp:66-73
+    return c == 8204959 || c == 30894 || c == 15219528 || c == 15231913 || c == 4646984 || c == 16741671 || c == 7566712 || c == 0;
+}
+
+extern "C" const char* goicp_engine_last_error(const goicp_engine* h) { return h ? h->err.c_str() : "null handle"; }
+
+extern "C" void goicp_engine_destroy(goicp_engine* h) {
+    if (!h) return;
+    hipSetDevice(h->device);
+    for (void* p : h->allocs) hipFree(p);
+    if (h->d_heaps) hipFree(h->d_heaps);
+    if (h->d_fpscratch) hipFree(h->d_fpscratch);
+    if (h->ev0) hipEventDestroy(h->ev0);
+    if (h->ev1) hipEventDestroy(h->ev1);
+    if (h->stream) hipStreamDestroy(h->stream);
+    delete h;
+}
+
+static void pick_geometry(goicp_engine* h) {
+    const int Nd = h->T.Nd;
+    if (Nd <= 256) { h->block = 256; h->ppt = 1; }
+    else if (Nd <= 512) { h->block = 256; h->ppt = 2; }
+    else if (Nd <= 1024) { h->block = 1024; h->ppt = 1; }
+    else if (Nd <= 2048) { h->block = 1024; h->ppt = 2; }
+    else if (Nd <= 4096) { h->block = 1024; h->ppt = 4; }
+    else { h->block = 1024; h->ppt = 8; }
+    h->dyn_lds = (h->T.exact && !h->T.doTrim) ? (size_t)TC * Nd * sizeof(float) : 0;
+}
+
+extern "C" int goicp_engine_create(const goicp_engine_desc* d, goicp_engine** out) {
+    if (!d || !out) return GOICP_ERR_ARG;
+    *out = nullptr;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || d->device_id < 0 || d->device_id >= ndev) return GOICP_ERR_NO_DEVICE;
+    if (d->S <= 0 || !d->dt_dist || d->Nd <= 0 || !d->data_xyz || !d->weights || !d->maxRotDis || d->Nm < 0) return GOICP_ERR_ARG;
+    if (d->regularizationNeighbors > 0.f) return GOICP_ERR_ARG;
+    if (d->Nd > 8192) return GOICP_ERR_ARG;       // register-resident cloud: 1024 lanes x 8 points
+    if (d->doTrim && (d->inlierNum < 1 || d->inlierNum > d->Nd)) return GOICP_ERR_ARG;
+    const bool use_compat = d->regularization > 0.f;
+    const bool use_fpfh = d->regularizationFPFH > 0.f;        // entered for any cfpfh once regularizationFPFH>0 (jly_goicp.cpp:460)
+    const bool have_tables = d->nearest_occ && d->cell_color && d->cell_ptr && d->cell_idx && d->model_color && d->data_color;
+    if ((use_compat || use_fpfh) && !have_tables) return GOICP_ERR_ARG;
+    if (use_fpfh && (!d->model_fpfh || !d->data_fpfh)) return GOICP_ERR_ARG;
+
+    goicp_engine* h = new goicp_engine();
+    memset(&h->T, 0, sizeof h->T);
+    h->device = d->device_id; h->stream = nullptr; h->ev0 = h->ev1 = nullptr;
+    h->d_heaps = nullptr; h->d_fpscratch = nullptr; h->heap_cap = 0; h->heap_jobs = 0; h->fp_blocks = 0;
+    h->n_cubes = h->n_lookups = 0; h->kernel_ms = 0; h->max_pops = 200000000u;
+#define CR(call) do { int rc_ = (call); if (rc_ != GOICP_OK) { std::string m = h->err; goicp_engine_destroy(h); fprintf(stderr, "goicp_engine_create: %s\n", m.c_str()); return rc_; } } while (0)
+#define CRH(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { fprintf(stderr, "goicp_engine_create: %s: %s\n", #call, hipGetErrorString(e_)); goicp_engine_destroy(h); return GOICP_ERR_NO_DEVICE; } } while (0)
+    CRH(hipSetDevice(h->device));
+    CRH(hipStreamCreate(&h->stream));
+    CRH(hipEventCreate(&h->ev0));
+    CRH(hipEventCreate(&h->ev1));
+    DevTables& T = h->T;
+    T.S = d->S; T.xMin = d->xMin; T.yMin = d->yMin; T.zMin = d->zMin; T.scale = d->scale;
+    T.Nd = d->Nd; T.Nm = d->Nm; T.doTrim = d->doTrim ? 1 : 0; T.inlierNum = d->doTrim ? d->inlierNum : d->Nd; T.norm = d->norm;
+    T.b0 = 0; T.b1 = 0;
+    if (d->cfpfh == 1) { T.b0 = 0; T.b1 = 41; } else if (d->cfpfh == 2) { T.b0 = 0; T.b1 = 33; } else if (d->cfpfh == 3) { T.b0 = 33; T.b1 = 41; }
+    T.reg = d->regularization; T.regFPFH = d->regularizationFPFH;
+    T.use_compat = use_compat; T.use_fpfh = use_fpfh;
+    T.exact = (d->parity_mode && d->Nd <= 1536) ? 1 : 0;   // TC*Nd floats of LDS next to the static tile state
+    const size_t ncell = (size_t)d->S * d->S * d->S;
+    float* p_dist; CR(dev_upload(h, d->dt_dist, ncell, &p_dist)); T.dist = p_dist;
+    float* p_dxyz; CR(dev_upload(h, d->data_xyz, (size_t)3 * d->Nd, &p_dxyz)); T.dxyz = p_dxyz;
+    float* p_w; CR(dev_upload(h, d->weights, (size_t)d->Nd, &p_w)); T.weights = p_w;
+    float* p_mrd; CR(dev_upload(h, d->maxRotDis, (size_t)GOICP_MAXROTLEVEL * d->Nd, &p_mrd)); T.maxRotDis = p_mrd;
+    CR(dev_upload(h, d->model_xyz, (size_t)3 * d->Nm, &h->d_mxyz));
+
+    // colour classes: the 8 known properties first, then whatever else appears (<= 16 classes in all)
+    std::map<int, int> cls;
+    auto cls_of = [&](int c) -> int {
+        auto it = cls.find(c);
+        if (it != cls.end()) return it->second;
+        int id = (int)cls.size(); cls[c] = id; return id;
+    };
+    std::vector<uint8_t> dcls(d->Nd, 0);
+    if (d->data_color) for (int i = 0; i < d->Nd; i++) dcls[i] = (uint8_t)cls_of(d->data_color[i]);
+    if (have_tables) {      // the compat mask also serves goicp_engine_point_eval when no penalty is active
+        std::vector<int> mcls(d->Nm);
+        for (int i = 0; i < d->Nm; i++) mcls[i] = cls_of(d->model_color[i]);
+        if (cls.size() > 16) { h->err = "more than 16 distinct colour codes"; CR(GOICP_ERR_ARG); }
+        // compat mask per cell, resolving emptyCells -> cellPoints (reference jly_goicp.cpp:986-1000,1068-1092)
+        std::vector<uint16_t> cmask(ncell, 0);
+        std::vector<int> occ(ncell, -1), occ_id(ncell, -1), occ_ptr(1, 0), occ_pts;
+        for (size_t k = 0; k < ncell; k++) {
+            if (d->cell_color[k] == -2) continue;
+            occ_id[k] = (int)occ_ptr.size() - 1;
+            for (int p = d->cell_ptr[k]; p < d->cell_ptr[k + 1]; p++) occ_pts.push_back(d->cell_idx[p]);
+            occ_ptr.push_back((int)occ_pts.size());
+        }
+        for (size_t k = 0; k < ncell; k++) {
+            const int nk = d->nearest_occ[k];
+            if (nk < 0 || (size_t)nk >= ncell) { h->err = "nearest_occ out of range"; CR(GOICP_ERR_ARG); }
+            const int col = d->cell_color[nk];
+            uint16_t m = 0;
+            if (col == -1) { for (int p = d->cell_ptr[nk]; p < d->cell_ptr[nk + 1]; p++) m |= (uint16_t)(1u << mcls[d->cell_idx[p]]); }
+            else if (col != -2 && known_prop(col)) { auto it = cls.find(col); if (it != cls.end()) m = (uint16_t)(1u << it->second); }
+            cmask[k] = m;
+            occ[k] = occ_id[nk];
+        }
+        uint16_t* p_cm; CR(dev_upload(h, cmask.data(), ncell, &p_cm)); T.cmask = p_cm;
+        if (use_fpfh) {
+            int* p_occ; CR(dev_upload(h, occ.data(), ncell, &p_occ)); T.occ = p_occ;
+            int* p_op; CR(dev_upload(h, occ_ptr.data(), occ_ptr.size(), &p_op)); T.occ_ptr = p_op;
+            int* p_oi; CR(dev_upload(h, occ_pts.data(), occ_pts.size(), &p_oi)); T.occ_pts = p_oi;
+            float* p_mf; CR(dev_upload(h, d->model_fpfh, (size_t)GOICP_FPFH_BINS * d->Nm, &p_mf)); T.mfpfh = p_mf;
+            float* p_df; CR(dev_upload(h, d->data_fpfh, (size_t)GOICP_FPFH_BINS * d->Nd, &p_df)); T.dfpfh = p_df;
+        }
+    }
+    if (cls.size() > 16) { h->err = "more than 16 distinct colour codes"; CR(GOICP_ERR_ARG); }
+    uint8_t* p_dc; CR(dev_upload(h, dcls.data(), (size_t)d->Nd, &p_dc)); T.dcls = p_dc;
+
+    h->nslots = 16;
+    CR(dev_upload<float4>(h, nullptr, (size_t)h->nslots * d->Nd, &h->d_rot));
+    CR(dev_upload<float>(h, nullptr, 16, &h->d_R));
+    h->job_cap = 4096;
+    CR(dev_upload<goicp_bnb_job>(h, nullptr, h->job_cap, &h->d_jobs));
+    CR(dev_upload<goicp_bnb_result>(h, nullptr, h->job_cap, &h->d_results));
+    h->cube_cap = 1 << 16;
+    CR(dev_upload<float>(h, nullptr, (size_t)4 * h->cube_cap, &h->d_cubes));
+    CR(dev_upload<float>(h, nullptr, h->cube_cap, &h->d_ub));
+    CR(dev_upload<float>(h, nullptr, h->cube_cap, &h->d_lb));
+    CR(dev_upload<double>(h, nullptr, 12, &h->d_Rt));
+    CR(dev_upload<float>(h, nullptr, 12, &h->d_Rtf));
+    CR(dev_upload<float>(h, nullptr, d->Nd, &h->d_dist));
+    CR(dev_upload<int>(h, nullptr, d->Nd, &h->d_int));
+    h->lat_cap = 1 << 14;
+    CR(dev_upload<float>(h, nullptr, (size_t)3 * h->lat_cap, &h->d_lat));
+    CR(dev_upload<int>(h, nullptr, h->lat_cap, &h->d_cnt));
+    CR(dev_upload<float>(h, nullptr, h->lat_cap, &h->d_fp));
+    pick_geometry(h);
+    if (h->dyn_lds + sizeof(TileShm<1024>) + 64 > 160 * 1024) { h->err = "LDS budget exceeded"; CR(GOICP_ERR_ARG); }
+#undef CR
+#undef CRH
+    *out = h;
+    return GOICP_OK;
+}
+
+extern "C" int goicp_engine_num_slots(const goicp_engine* h) { return h ? h->nslots : 0; }
+extern "C" void* goicp_engine_stream(const goicp_engine* h) { return h ? (void*)h->stream : nullptr; }
+
+extern "C" int goicp_engine_synchronize(goicp_engine* h) {
+    if (!h) return GOICP_ERR_ARG;
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    return GOICP_OK;
+}
+
+extern "C" int goicp_engine_stats(const goicp_engine* h, uint64_t* cube_evals, uint64_t* lookups, double* kernel_ms) {
+    if (!h) return GOICP_ERR_ARG;
+    if (cube_evals) *cube_evals = h->n_cubes;
+    if (lookups) *lookups = h->n_lookups;
+    if (kernel_ms) *kernel_ms = h->kernel_ms;
+    return GOICP_OK;
+}
+
+extern "C" int goicp_engine_set_rotation(goicp_engine* h, int slot, const float* R9) {
+    if (!h || !R9 || slot < 0 || slot >= h->nslots) return GOICP_ERR_ARG;
+    HIPCHK(h, hipSetDevice(h->device));
+    HIPCHK(h, hipMemcpyAsync(h->d_R, R9, 9 * sizeof(float), hipMemcpyHostToDevice, h->stream));
+    hipLaunchKernelGGL(k_rotate, dim3((h->T.Nd + 255) / 256), dim3(256), 0, h->stream, h->T, h->d_R, h->d_rot + (size_t)slot * h->T.Nd);
+    HIPCHK(h, hipGetLastError());
+    HIPCHK(h, hipStreamSynchronize(h->stream));      // d_R is reused by the next call
+    return GOICP_OK;
+}
+
+static int ensure_fpscratch(goicp_engine* h, size_t blocks) {
+    if (!h->T.use_fpfh) return GOICP_OK;
+    if (blocks <= h->fp_blocks) return GOICP_OK;
+    if (h->d_fpscratch) { HIPCHK(h, hipStreamSynchronize(h->stream)); hipFree(h->d_fpscratch); h->d_fpscratch = nullptr; h->fp_blocks = 0; }
+    HIPCHK(h, hipMalloc((void**)&h->d_fpscratch, blocks * NLMAX * (size_t)h->T.Nd * sizeof(float)));
+    h->fp_blocks = blocks;
+    return GOICP_OK;
+}
+
+#define DISPATCH_GEOM(h, CALL)                                               \
+    do {                                                                     \
+        if (h->block == 256 && h->ppt == 1) { CALL(256, 1); }                \
+        else if (h->block == 256 && h->ppt == 2) { CALL(256, 2); }           \
+        else if (h->block == 1024 && h->ppt == 1) { CALL(1024, 1); }         \
+        else if (h->block == 1024 && h->ppt == 2) { CALL(1024, 2); }         \
+        else if (h->block == 1024 && h->ppt == 4) { CALL(1024, 4); }         \
+        else { CALL(1024, 8); }                                              \
+    } while (0)
+
+extern "C" int goicp_engine_eval_cubes_dev(goicp_engine* h, int slot, int rot_level, const void* cubes_dev, int n, void* ub_dev, void* lb_dev) {
+    if (!h || slot < 0 || slot >= h->nslots || rot_level >= GOICP_MAXROTLEVEL || n < 0 || (n && (!cubes_dev || !ub_dev || !lb_dev))) return GOICP_ERR_ARG;
+    if (n == 0) return GOICP_OK;
+    HIPCHK(h, hipSetDevice(h->device));
+    const int tiles = (n + TC - 1) / TC;
+    int rc = ensure_fpscratch(h, (size_t)tiles);
+    if (rc != GOICP_OK) return rc;
+    const float4* rot = h->d_rot + (size_t)slot * h->T.Nd;
+#define CALL(B, P) hipLaunchKernelGGL((k_eval_cubes<B, P>), dim3(tiles), dim3(B), h->dyn_lds, h->stream, h->T, rot, rot_level, (const float*)cubes_dev, n, (float*)ub_dev, (float*)lb_dev, h->d_fpscratch)
+    DISPATCH_GEOM(h, CALL);
+#undef CALL
+    HIPCHK(h, hipGetLastError());
+    h->n_cubes += (uint64_t)n; h->n_lookups += (uint64_t)n * h->T.Nd;
+    return GOICP_OK;
+}
+
+extern "C" int goicp_engine_eval_cubes(goicp_engine* h, int slot, int rot_level, const float* cubes, int n, float* ub, float* lb) {
+    if (!h || n < 0 || (n && (!cubes || !ub || !lb))) return GOICP_ERR_ARG;
+    for (int off = 0; off < n; off += h->cube_cap) {
+        const int m = std::min(h->cube_cap, n - off);
+        HIPCHK(h, hipMemcpyAsync(h->d_cubes, cubes + (size_t)4 * off, (size_t)4 * m * sizeof(float), hipMemcpyHostToDevice, h->stream));
+        HIPCHK(h, hipEventRecord(h->ev0, h->stream));
+        int rc = goicp_engine_eval_cubes_dev(h, slot, rot_level, h->d_cubes, m, h->d_ub, h->d_lb);
+        if (rc != GOICP_OK) return rc;
+        HIPCHK(h, hipEventRecord(h->ev1, h->stream));
+        HIPCHK(h, hipMemcpyAsync(ub + off, h->d_ub, (size_t)m * sizeof(float), hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(h, hipMemcpyAsync(lb + off, h->d_lb, (size_t)m * sizeof(float), hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(h, hipStreamSynchronize(h->stream));
+        float ms = 0.f; hipEventElapsedTime(&ms, h->ev0, h->ev1); h->kernel_ms += ms;
+    }
+    return GOICP_OK;
+}
+
+extern "C" int goicp_engine_corner_terms(goicp_engine* h, int slot, const float* xyz, int n, int32_t* incompat, float* fpfh) {
+    if (!h || slot < 0 || slot >= h->nslots || n < 0 || (n && !xyz)) return GOICP_ERR_ARG;
+    HIPCHK(h, hipSetDevice(h->device));
+    const float4* rot = h->d_rot + (size_t)slot * h->T.Nd;
+    for (int off = 0; off < n; off += h->lat_cap) {
+        const int m = std::min(h->lat_cap, n - off);
+        const int blocks = (m + NLMAX - 1) / NLMAX;
+        int rc = ensure_fpscratch(h, (size_t)blocks);
+        if (rc != GOICP_OK) return rc;
+        HIPCHK(h, hipMemcpyAsync(h->d_lat, xyz + (size_t)3 * off, (size_t)3 * m * sizeof(float), hipMemcpyHostToDevice, h->stream));
+#define CALL(B, P) hipLaunchKernelGGL((k_corner_terms<B, P>), dim3(blocks), dim3(B), 0, h->stream, h->T, rot, h->d_lat, m, h->d_cnt, h->d_fp, h->d_fpscratch)
+        DISPATCH_GEOM(h, CALL);
+#undef CALL
+        HIPCHK(h, hipGetLastError());
+        if (incompat) HIPCHK(h, hipMemcpyAsync(incompat + off, h->d_cnt, (size_t)m * sizeof(int), hipMemcpyDeviceToHost, h->stream));
+        if (fpfh) HIPCHK(h, hipMemcpyAsync(fpfh + off, h->d_fp, (size_t)m * sizeof(float), hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(h, hipStreamSynchronize(h->stream));
+    }
+    return GOICP_OK;
+}
+
+static int ensure_heaps(goicp_engine* h, size_t jobs, int cap) {
+    if (h->d_heaps && jobs <= h->heap_jobs && cap <= h->heap_cap) return GOICP_OK;
+    if (h->d_heaps) { HIPCHK(h, hipStreamSynchronize(h->stream)); hipFree(h->d_heaps); h->d_heaps = nullptr; }
+    size_t nj = std::max(jobs, h->heap_jobs);
+    int nc = std::max(cap, h->heap_cap);
+    HIPCHK(h, hipMalloc((void**)&h->d_heaps, nj * (size_t)nc * sizeof(HeapNode)));
+    h->heap_jobs = nj; h->heap_cap = nc;
+    return GOICP_OK;
+}
+
+static int run_bnb(goicp_engine* h, const goicp_bnb_job* jobs, int njobs, goicp_bnb_result* results, int cap) {
+    int rc = ensure_heaps(h, (size_t)njobs, cap);
+    if (rc != GOICP_OK) return rc;
+    rc = ensure_fpscratch(h, (size_t)njobs);
+    if (rc != GOICP_OK) return rc;
+    HIPCHK(h, hipMemcpyAsync(h->d_jobs, jobs, (size_t)njobs * sizeof(goicp_bnb_job), hipMemcpyHostToDevice, h->stream));
+    HIPCHK(h, hipEventRecord(h->ev0, h->stream));
+#define CALL(B, P) hipLaunchKernelGGL((k_inner_bnb<B, P>), dim3(njobs), dim3(B), h->dyn_lds, h->stream, h->T, h->d_jobs, h->d_results, h->d_heaps, h->heap_cap, h->d_fpscratch, h->max_pops)
+    DISPATCH_GEOM(h, CALL);
+#undef CALL
+    HIPCHK(h, hipGetLastError());
+    HIPCHK(h, hipEventRecord(h->ev1, h->stream));
+    HIPCHK(h, hipMemcpyAsync(results, h->d_results, (size_t)njobs * sizeof(goicp_bnb_result), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    float ms = 0.f; hipEventElapsedTime(&ms, h->ev0, h->ev1); h->kernel_ms += ms;
+    return GOICP_OK;
+}
+
+extern "C" int goicp_engine_inner_bnb_batch(goicp_engine* h, const goicp_bnb_job* jobs, int njobs, goicp_bnb_result* results) {
+    if (!h || njobs < 0 || (njobs && (!jobs || !results))) return GOICP_ERR_ARG;
+    HIPCHK(h, hipSetDevice(h->device));
+    for (int j = 0; j < njobs; j++) if (jobs[j].rot_level >= GOICP_MAXROTLEVEL) return GOICP_ERR_ARG;
+    int worst = GOICP_OK;
+    for (int off = 0; off < njobs; off += h->job_cap) {
+        const int m = std::min(h->job_cap, njobs - off);
+        int rc = run_bnb(h, jobs + off, m, results + off, std::max(h->heap_cap, 8192));
+        if (rc != GOICP_OK) return rc;
+        for (int j = 0; j < m; j++) {
+            goicp_bnb_result& r = results[off + j];
+            // a job whose queue outgrew its slab is re-run alone with a larger one (the search is deterministic)
+            int cap = h->heap_cap;
+            while (r.status == GOICP_ERR_OVERFLOW && cap < (1 << 24)) {
+                cap *= 16;
+                rc = run_bnb(h, jobs + off + j, 1, &r, cap);
+                if (rc != GOICP_OK) return rc;
+            }
+            h->n_cubes += r.cube_evals; h->n_lookups += (uint64_t)r.cube_evals * h->T.Nd;
+            if (r.status != GOICP_OK) worst = r.status;
+        }
+    }
+    return worst;
+}
+
+extern "C" int goicp_engine_inner_bnb(goicp_engine* h, const goicp_bnb_job* job, goicp_bnb_result* result) {
+    return goicp_engine_inner_bnb_batch(h, job, 1, result);
+}
+
+extern "C" int goicp_engine_point_eval(goicp_engine* h, const double* R9, const double* t3, float* dist, int32_t* compat) {
+    if (!h || !R9 || !t3 || !dist) return GOICP_ERR_ARG;
+    HIPCHK(h, hipSetDevice(h->device));
+    double Rt[12]; memcpy(Rt, R9, 9 * sizeof(double)); memcpy(Rt + 9, t3, 3 * sizeof(double));
+    HIPCHK(h, hipMemcpyAsync(h->d_Rt, Rt, sizeof Rt, hipMemcpyHostToDevice, h->stream));
+    hipLaunchKernelGGL(k_point_eval, dim3((h->T.Nd + 255) / 256), dim3(256), 0, h->stream, h->T, h->d_Rt, h->d_dist, compat ? h->d_int : nullptr);
+    HIPCHK(h, hipGetLastError());
+    HIPCHK(h, hipMemcpyAsync(dist, h->d_dist, (size_t)h->T.Nd * sizeof(float), hipMemcpyDeviceToHost, h->stream));
+    if (compat) HIPCHK(h, hipMemcpyAsync(compat, h->d_int, (size_t)h->T.Nd * sizeof(int), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    h->n_lookups += (uint64_t)h->T.Nd;
+    return GOICP_OK;
+}
+
+extern "C" int goicp_engine_icp_nn(goicp_engine* h, const double* R9, const double* t3, int32_t* id_model, float* dist_sq) {
+    if (!h || !R9 || !t3 || !id_model || !dist_sq || h->T.Nm <= 0) return GOICP_ERR_ARG;
+    HIPCHK(h, hipSetDevice(h->device));
+    float Rt[12];
+    for (int k = 0; k < 9; k++) Rt[k] = (float)R9[k];
+    for (int k = 0; k < 3; k++) Rt[9 + k] = (float)t3[k];
+    HIPCHK(h, hipMemcpyAsync(h->d_Rtf, Rt, sizeof Rt, hipMemcpyHostToDevice, h->stream));
+    hipLaunchKernelGGL(k_icp_nn, dim3((h->T.Nd + 255) / 256), dim3(256), 0, h->stream, h->T, h->d_mxyz, h->d_Rtf, h->d_int, h->d_dist);
+    HIPCHK(h, hipGetLastError());
+    HIPCHK(h, hipMemcpyAsync(id_model, h->d_int, (size_t)h->T.Nd * sizeof(int), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipMemcpyAsync(dist_sq, h->d_dist, (size_t)h->T.Nd * sizeof(float), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    return GOICP_OK;
+}

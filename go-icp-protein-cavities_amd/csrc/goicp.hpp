@@ -1,0 +1,144 @@
+// goicp.hpp -- host-side mirror of the reference's registration API for the accelerated path.
+//
+// Same class name, public fields and call sequence as the reference's `class GoICP`
+// (reference jly_goicp.h:112-218; caller: jly_main.cpp:61-139): default-construct, fill the public
+// configuration fields, assign pModel/Nm/pData/Nd, BuildDT(), optionally lower Nd, Register(), then read
+// optR / optT / optError / optComp.  The outer rotation branch-and-bound stays on the host (this file's
+// .cpp); every error evaluation goes through the C ABI of include/goicp_engine.h to the HIP kernels.
+// There is no CPU evaluation path: Register() returns NaN and sets `status` when no MI355X is usable.
+#ifndef GOICP_HPP
+#define GOICP_HPP
+
+#include <cstdint>
+#include <iosfwd>
+#include <string>
+#include <vector>
+
+#include "goicp_engine.h"
+
+namespace goicp {
+
+constexpr double PI = 3.1415926536;       // reference jly_goicp.h:44
+constexpr double SQRT3 = 1.732050808;     // reference jly_goicp.h:45
+constexpr int MAXROTLEVEL = 20;           // reference jly_goicp.h:95
+
+// physico-chemical property codes (reference transformation.hpp:36)
+enum properties { OG = 8204959, N = 30894, O = 15219528, NZ = 15231913, CZ = 4646984, CA = 16741671, DU = 7566712, OD1 = 0, C = 1 };
+properties string_to_prop(const std::string& type);   // reference transformation.cpp:18-47
+
+struct POINT3D {                          // reference jly_goicp.h:47-56
+    float x = 0, y = 0, z = 0;
+    int c = 0;
+    int neighbors = 0;
+    float density = 0;
+    std::vector<float> cfpfh;
+};
+
+struct ROTNODE { float a, b, c, w; float ub, lb; int l; };      // reference jly_goicp.h:59-73
+struct TRANSNODE { float x, y, z, w; float ub, lb; };           // reference jly_goicp.h:75-87
+
+// minimal stand-in for the reference's Matrix results (`optR.val[i][j]`, `optT.val[i][0]`, operator<<
+// printing "%12.7f " per element -- reference matrix.cpp:812-827)
+struct Matrix {
+    int m = 0, n = 0;
+    double val[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}};
+    Matrix() {}
+    Matrix(int m_, int n_) : m(m_), n(n_) {}
+    static Matrix eye(int k) { Matrix M(k, k); for (int i = 0; i < k; i++) M.val[i][i] = 1; return M; }
+};
+std::ostream& operator<<(std::ostream& out, const Matrix& M);
+
+// Distance transform + cell tables (reference jly_3ddt.h:112-139), flattened x-fastest for staging to HBM.
+class DT3D {
+public:
+    int SIZE = 300;                        // reference jly_3ddt.cpp (DT3D::DT3D) default via config
+    double scale = 0;
+    double expandFactor = 2.0;
+    double xMin = 0, xMax = 0, yMin = 0, yMax = 0, zMin = 0, zMax = 0;
+    void Build(const double* x, const double* y, const double* z, int num);   // reference jly_3ddt.cpp:897-1137
+    std::vector<float> dist;               // [S^3] A.data[z][y][x].distance
+    std::vector<int32_t> nearest;          // [S^3] emptyCells -> linear index of the nearest occupied cell
+    std::vector<int32_t> cell_color;       // [S^3] cellPoints[].c  (-2 empty, -1 mixed after assignCellColor)
+    std::vector<int32_t> cell_ptr;         // [S^3+1] CSR of cellPoints[].points
+    std::vector<int32_t> cell_idx;
+};
+
+struct RegisterStats {
+    uint64_t rot_pops = 0, inner_calls = 0, inner_launches = 0, inner_jobs_launched = 0, cube_evals = 0, trans_pops = 0, icp_calls = 0, icp_iters = 0;
+    double engine_kernel_ms = 0;
+};
+
+class GoICP {
+public:
+    int Nm = 0, Nd = 0;
+    POINT3D* pModel = nullptr;
+    POINT3D* pData = nullptr;
+
+    ROTNODE initNodeRot;
+    TRANSNODE initNodeTrans;
+    DT3D dt;
+    ROTNODE optNodeRot;
+    TRANSNODE optNodeTrans;
+
+    GoICP();
+    ~GoICP();
+    float Register();
+    void BuildDT();
+
+    float MSEThresh = 0.001f;
+    float SSEThresh = 0;
+    float icpThresh = 0;
+    float optError = 0;
+    Matrix optR;
+    Matrix optT;
+    float trimFraction = 0;
+    int inlierNum = 0;
+    bool doTrim = true;
+
+    float regularization = 0;
+    float regularizationNeighbors = 0;
+    float regularizationFPFH = 0;
+    int optComp = 0;
+    int norm = 2;
+    int ponderation = 0;
+    int cfpfh = 0;
+
+    // --- additions of this build (not in the reference) ---
+    int device_id = 0;
+    int parity_mode = 1;          // see goicp_engine_desc::parity_mode
+    int speculate = 1;            // batch the <=16 InnerBnB calls of one rotation pop into one launch
+    int verbose = 0;              // echo the reference's "Error*: ..." progress lines to stdout
+    int status = GOICP_OK;        // last engine status
+    std::string error_message;
+    RegisterStats stats;
+    std::vector<std::pair<std::string, float>> trace;   // ("Init"|"ICP"|"BNB", Error*) in order
+
+    // state shared with tests through the C API
+    std::vector<float> weights;            // [Nd]
+    std::vector<float> maxRotDis;          // [20*Nd]
+    void Initialize();                     // reference jly_goicp.cpp:180-267 (+ engine creation)
+    void Clear();
+    goicp_engine* engine() { return eng_; }
+    float ICP(Matrix& R_icp, Matrix& t_icp);                      // reference jly_goicp.cpp:102-178
+    float InnerBnB(const float* R9, int rot_level, TRANSNODE* nodeTransOut);   // reference jly_goicp.cpp:286-579 (one job)
+
+private:
+    goicp_engine* eng_ = nullptr;
+    std::vector<float> normData_, minDis_;
+    std::vector<int32_t> icp_id_data_, icp_id_model_, opt_id_data_, opt_id_model_;
+    float OuterBnB();                      // reference jly_goicp.cpp:582-876
+    float icp_run(Matrix& R, Matrix& t);   // reference jly_icp3d.hpp:197-311 (1-NN on the device)
+    void neighborsWeights();               // reference jly_goicp.cpp:1453-1498
+    int countCompatibilities(const std::vector<int32_t>& id_data, const std::vector<int32_t>& id_model) const;   // :890-914
+    int updateCompatibilities();           // reference jly_goicp.cpp:933-946
+    void assignCellColor();                // reference jly_goicp.cpp:951-969
+    void log_error(const char* tag, float v);
+};
+
+// jly_sorting.hpp:229-313 restated (the permutation fixes the float summation order of trimmed sums)
+void intro_select(float* data, size_t st, size_t en, size_t k);
+// V*diag(1,1,det)*U^T of the cross-covariance H = U W V^T (jly_icp3d.hpp:283-303)
+void kabsch_rotation(const double H[9], double Rout[9]);
+
+}  // namespace goicp
+#endif

@@ -1,0 +1,581 @@
+// host_goicp.cpp -- GoICP::Register() / BuildDT() with the reference's control flow on the host and every
+// error evaluation on the MI355X through include/goicp_engine.h.
+//
+// Host-side pieces restated from the reference (float/double mixing kept expression by expression, see
+// SURVEY.md 8(a')): Initialize (jly_goicp.cpp:180-267), neighborsWeights (:1453-1498), OuterBnB (:582-876),
+// ICP (:102-178), ICP3D::Run's iteration (jly_icp3d.hpp:197-311) with the 1-NN search on the device.
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <iostream>
+#include <limits>
+
+#include "goicp.hpp"
+
+namespace goicp {
+
+properties string_to_prop(const std::string& t) {
+    if (t == "OG") return OG; if (t == "N") return N; if (t == "O") return O; if (t == "NZ") return NZ;
+    if (t == "CZ") return CZ; if (t == "CA") return CA; if (t == "DU") return DU; if (t == "OD1") return OD1;
+    if (t == "C") return C;
+    return OG;
+}
+
+std::ostream& operator<<(std::ostream& out, const Matrix& M) {
+    if (M.m == 0 || M.n == 0) { out << "[empty matrix]"; return out; }
+    char buf[64];
+    for (int i = 0; i < M.m; i++) {
+        for (int j = 0; j < M.n; j++) { snprintf(buf, sizeof buf, "%12.7f ", M.val[i][j]); out << buf; }
+        if (i < M.m - 1) out << std::endl;
+    }
+    return out;
+}
+
+static bool known_prop(int c) {   // keys of the identity compatibility map (reference jly_goicp.cpp:66-73)
+    return c == OG || c == N || c == O || c == NZ || c == CZ || c == CA || c == DU || c == OD1;
+}
+
+// -------------------------------------------------------------------------------------------------
+// selection with the reference's swap sequence (jly_sorting.hpp:34-313)
+// -------------------------------------------------------------------------------------------------
+namespace {
+size_t pivot_ends(const float* d, size_t s, size_t e) {
+    const size_t m = (s + e) / 2;
+    if (d[s] < d[e]) return d[m] < d[s] ? s : (d[m] < d[e] ? m : e);
+    return d[m] < d[e] ? e : (d[m] < d[s] ? m : s);
+}
+size_t median3(const float* d, size_t s) {
+    const float* q = d + s;
+    if (q[0] < q[2]) return q[1] < q[0] ? s : (q[1] < q[2] ? s + 1 : s + 2);
+    return d[1] < d[2] ? s + 2 : (d[1] < d[0] ? s + 1 : s);     // absolute indices, as in jly_sorting.hpp:74-80
+}
+size_t median5(float* d, size_t s) {
+    float* q = d + s; float t;
+    if (q[0] > q[1]) std::swap(q[0], q[1]);
+    if (q[2] > q[3]) std::swap(q[2], q[3]);
+    if (q[0] < q[2]) { t = q[4]; q[4] = q[0]; if (t < q[1]) q[0] = t; else { q[0] = q[1]; q[1] = t; } }
+    else { t = q[4]; q[4] = q[2]; if (t < q[3]) q[2] = t; else { q[2] = q[3]; q[3] = t; } }
+    if (q[0] < q[2]) return q[1] < q[2] ? s + 1 : s + 2;
+    return q[0] < q[3] ? s : s + 3;
+}
+size_t median_of_medians(float* d, size_t s, size_t e) {
+    const size_t len = e - s + 1, groups = len / 5 + (len % 5 != 0);
+    size_t g = s, i = 0, mi;
+    for (; i + 1 < groups; i++, g += 5) { mi = median5(d, g); std::swap(d[s + i], d[mi]); }
+    switch (e - g + 1) { case 3: case 4: mi = median3(d, g); break; case 5: mi = median5(d, g); break; default: mi = g; }
+    std::swap(d[s + i], d[mi]);
+    if (groups > 5) return median_of_medians(d, s, s + groups - 1);
+    switch (groups) { case 3: case 4: return median3(d, s); case 5: return median5(d, s); default: return s; }
+}
+}  // namespace
+
+void intro_select(float* d, size_t s, size_t e, size_t k) {
+    size_t prev = e - s + 1, tries = 0;
+    bool quick = true;
+    for (;;) {
+        if (s >= e) return;
+        if (e - s <= 5) {
+            for (size_t i = s + 1; i <= e; i++) for (size_t j = i; j > s && d[j - 1] > d[j]; j--) std::swap(d[j - 1], d[j]);
+            return;
+        }
+        if (quick && tries++ == 5) { const size_t len = e - s + 1; if (len * 2 > prev) quick = false; prev = len; tries = 0; }
+        const size_t pi = quick ? pivot_ends(d, s, e) : median_of_medians(d, s, e);
+        if (pi != s) std::swap(d[s], d[pi]);
+        const float piv = d[s];
+        size_t lo = s + 1, hi = e;
+        for (;;) {
+            while (lo < hi && piv >= d[lo]) ++lo;
+            while (lo < hi && piv <= d[hi]) --hi;
+            if (lo >= hi) break;
+            std::swap(d[lo], d[hi]);
+        }
+        const size_t sp = d[lo] < piv ? lo : lo - 1;
+        d[s] = d[sp]; d[sp] = piv;
+        if (sp < k) s = sp + 1; else if (sp > k) e = sp - 1; else return;
+    }
+}
+
+// -------------------------------------------------------------------------------------------------
+// 3x3 SVD (one-sided Jacobi) -> Kabsch rotation with the reference's float determinant (jly_icp3d.hpp:283-303)
+// -------------------------------------------------------------------------------------------------
+static void mul3(const double* A, const double* B, double* Cm) {
+    for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) { double s = 0; for (int k = 0; k < 3; k++) s += A[3 * i + k] * B[3 * k + j]; Cm[3 * i + j] = s; }
+}
+
+void kabsch_rotation(const double H[9], double Rout[9]) {
+    double A[9], V[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+    std::memcpy(A, H, sizeof A);
+    for (int sweep = 0; sweep < 60; sweep++) {
+        double off = 0;
+        for (int p = 0; p < 2; p++) for (int q = p + 1; q < 3; q++) {
+            double al = 0, be = 0, ga = 0;
+            for (int i = 0; i < 3; i++) { al += A[3 * i + p] * A[3 * i + p]; be += A[3 * i + q] * A[3 * i + q]; ga += A[3 * i + p] * A[3 * i + q]; }
+            if (ga == 0) continue;
+            off += std::fabs(ga) / std::sqrt(al * be + 1e-300);
+            const double zeta = (be - al) / (2 * ga);
+            const double t = (zeta >= 0 ? 1.0 : -1.0) / (std::fabs(zeta) + std::sqrt(1 + zeta * zeta));
+            const double cs = 1 / std::sqrt(1 + t * t), sn = cs * t;
+            for (int i = 0; i < 3; i++) {
+                const double ap = A[3 * i + p], aq = A[3 * i + q]; A[3 * i + p] = cs * ap - sn * aq; A[3 * i + q] = sn * ap + cs * aq;
+                const double vp = V[3 * i + p], vq = V[3 * i + q]; V[3 * i + p] = cs * vp - sn * vq; V[3 * i + q] = sn * vp + cs * vq;
+            }
+        }
+        if (off < 1e-15) break;
+    }
+    double w[3]; int ord[3] = {0, 1, 2};
+    for (int j = 0; j < 3; j++) w[j] = std::sqrt(A[j] * A[j] + A[3 + j] * A[3 + j] + A[6 + j] * A[6 + j]);
+    for (int a = 0; a < 2; a++) for (int b = a + 1; b < 3; b++) if (w[ord[b]] > w[ord[a]]) std::swap(ord[a], ord[b]);
+    double U[9], Vs[9], W[3];
+    for (int j = 0; j < 3; j++) {
+        const int s = ord[j]; W[j] = w[s];
+        for (int i = 0; i < 3; i++) { Vs[3 * i + j] = V[3 * i + s]; U[3 * i + j] = w[s] > 0 ? A[3 * i + s] / w[s] : 0; }
+    }
+    if (!(W[2] > 1e-300 * (W[0] + 1))) {      // rank-deficient H: complete U to an orthonormal basis
+        if (!(W[1] > 1e-300 * (W[0] + 1))) {
+            double a0 = U[0], a1 = U[3], a2 = U[6];
+            if (a0 * a0 + a1 * a1 + a2 * a2 == 0) { U[0] = 1; U[3] = 0; U[6] = 0; a0 = 1; a1 = a2 = 0; }
+            double bx = std::fabs(a0) < 0.9 ? 1 : 0, by = std::fabs(a0) < 0.9 ? 0 : 1, bz = 0;
+            const double dp = bx * a0 + by * a1 + bz * a2; bx -= dp * a0; by -= dp * a1; bz -= dp * a2;
+            const double nb = std::sqrt(bx * bx + by * by + bz * bz); U[1] = bx / nb; U[4] = by / nb; U[7] = bz / nb;
+        }
+        U[2] = U[3] * U[7] - U[6] * U[4]; U[5] = U[6] * U[1] - U[0] * U[7]; U[8] = U[0] * U[4] - U[3] * U[1];
+    }
+    double Ut[9], R0[9], D[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1}, VD[9];
+    for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) Ut[3 * i + j] = U[3 * j + i];
+    mul3(Vs, Ut, R0);
+    const float a = (float)(R0[0] * (R0[4] * R0[8] - R0[5] * R0[7]));
+    const float b = (float)(-R0[1] * (R0[3] * R0[8] - R0[5] * R0[6]));
+    const float c = (float)(R0[2] * (R0[3] * R0[7] - R0[4] * R0[6]));
+    const float det = a + b + c;
+    D[8] = det;
+    mul3(Vs, D, VD); mul3(VD, Ut, Rout);
+}
+
+// -------------------------------------------------------------------------------------------------
+// binary heaps with std::priority_queue's element order (ties on (lb,w) are frequent)
+// -------------------------------------------------------------------------------------------------
+namespace {
+inline bool lower(const ROTNODE& p, const ROTNODE& q) { return p.lb != q.lb ? p.lb > q.lb : p.w < q.w; }   // jly_goicp.h:64-72
+
+struct RotHeap {
+    std::vector<ROTNODE> a;
+    bool empty() const { return a.empty(); }
+    const ROTNODE& top() const { return a[0]; }
+    void up(size_t hole, const ROTNODE& v) {
+        while (hole > 0) { const size_t par = (hole - 1) / 2; if (!lower(a[par], v)) break; a[hole] = a[par]; hole = par; }
+        a[hole] = v;
+    }
+    void push(const ROTNODE& v) { a.push_back(v); up(a.size() - 1, v); }
+    void pop() {
+        if (a.size() > 1) {
+            const long len = (long)a.size() - 1;
+            const ROTNODE v = a[len];
+            a[len] = a[0];
+            long hole = 0, child = 0;
+            while (child < (len - 1) / 2) { child = 2 * (child + 1); if (lower(a[child], a[child - 1])) child--; a[hole] = a[child]; hole = child; }
+            if ((len & 1) == 0 && child == (len - 2) / 2) { child = 2 * (child + 1); a[hole] = a[child - 1]; hole = child - 1; }
+            up((size_t)hole, v);
+        }
+        a.pop_back();
+    }
+};
+}  // namespace
+
+// -------------------------------------------------------------------------------------------------
+GoICP::GoICP() {
+    // reference jly_goicp.cpp:44-56
+    initNodeRot.a = (float)-PI; initNodeRot.b = (float)-PI; initNodeRot.c = (float)-PI; initNodeRot.w = (float)(2 * PI); initNodeRot.l = 0;
+    initNodeRot.lb = 0; initNodeRot.ub = 0;
+    initNodeTrans.x = initNodeTrans.y = initNodeTrans.z = -0.5f; initNodeTrans.w = 1.0f; initNodeTrans.lb = 0; initNodeTrans.ub = 0;
+    optNodeRot = initNodeRot; optNodeTrans = initNodeTrans;
+    optR = Matrix::eye(3); optT = Matrix(3, 1);
+    doTrim = true;
+}
+
+GoICP::~GoICP() { Clear(); }
+
+void GoICP::Clear() {
+    if (eng_) { goicp_engine_destroy(eng_); eng_ = nullptr; }
+}
+
+void GoICP::log_error(const char* tag, float v) {
+    trace.emplace_back(tag, v);
+    if (verbose) std::cout << "Error*: " << v << " (" << tag << ")" << std::endl;
+}
+
+// reference jly_goicp.cpp:79-99 + assignCellColor (:951-969)
+void GoICP::BuildDT() {
+    std::vector<double> x(Nm), y(Nm), z(Nm);
+    for (int i = 0; i < Nm; i++) { x[i] = pModel[i].x; y[i] = pModel[i].y; z[i] = pModel[i].z; }
+    dt.Build(x.data(), y.data(), z.data(), Nm);
+    assignCellColor();
+}
+
+void GoICP::assignCellColor() {
+    const size_t ncell = dt.cell_color.size();
+    for (size_t k = 0; k < ncell; k++) if (dt.cell_color[k] == -1) {
+        const int p0 = dt.cell_ptr[k], p1 = dt.cell_ptr[k + 1];
+        const int prop = pModel[dt.cell_idx[p0]].c;
+        bool mixed = false;
+        for (int p = p0 + 1; p < p1; p++) if (pModel[dt.cell_idx[p]].c != prop) { mixed = true; break; }
+        dt.cell_color[k] = mixed ? -1 : prop;
+    }
+}
+
+// reference jly_goicp.cpp:1453-1498 with isNeighbor (:1097-1103)
+void GoICP::neighborsWeights() {
+    int maxN = 0, minN = 100;
+    float radius = 0.035f;
+    int guard = 0;
+    while (maxN < 19) {
+        if (Nd < 20 && ++guard > 100000) break;      // the reference never terminates for Nd < 20
+        const double lim = (double)std::sqrt(radius);
+        for (int i = 0; i < Nd; i++) {
+            int cnt = 0;
+            for (int j = 0; j < Nd; j++) {
+                if (j == i) continue;
+                const double dx = (double)(pData[j].x - pData[i].x), dy = (double)(pData[j].y - pData[i].y), dz = (double)(pData[j].z - pData[i].z);
+                if (std::sqrt(dx * dx + dy * dy + dz * dz) < lim) cnt++;
+            }
+            pData[i].neighbors = cnt;
+            if (cnt > maxN) maxN = cnt;
+            if (cnt < minN) minN = cnt;
+        }
+        radius = (float)(radius + 0.001);
+    }
+    if (minN == 0) minN = 1;
+    for (int i = 0; i < Nd; i++) {
+        if (pData[i].neighbors == 0) pData[i].neighbors = 1;
+        const float f = ((float)minN / (float)pData[i].neighbors) * 2;
+        weights[i] += f;
+    }
+}
+
+// reference jly_goicp.cpp:180-267, then the tables are staged to the device
+void GoICP::Initialize() {
+    Clear();
+    status = GOICP_OK; error_message.clear();
+    normData_.resize(Nd);
+    for (int i = 0; i < Nd; i++) normData_[i] = std::sqrt(pData[i].x * pData[i].x + pData[i].y * pData[i].y + pData[i].z * pData[i].z);
+    maxRotDis.resize((size_t)MAXROTLEVEL * Nd);
+    for (int i = 0; i < MAXROTLEVEL; i++) {
+        const float sigma = (float)(initNodeRot.w / std::pow(2.0, i) / 2.0);
+        float maxAngle = (float)(SQRT3 * sigma);
+        if (maxAngle > PI) maxAngle = (float)PI;
+        for (int j = 0; j < Nd; j++) maxRotDis[(size_t)i * Nd + j] = 2 * std::sin(maxAngle / 2) * normData_[j];
+    }
+    minDis_.resize(Nd);
+    optNodeRot = initNodeRot; optNodeTrans = initNodeTrans;
+    optR = Matrix::eye(3); optT = Matrix(3, 1);
+    if (doTrim) inlierNum = (int)(Nd * (1 - trimFraction)); else inlierNum = Nd;
+    weights.assign(Nd, 1.0f);
+    if (ponderation == 1) neighborsWeights();
+    SSEThresh = MSEThresh * inlierNum;
+
+    // ---- stage everything the hot path reads into HBM (once per registration)
+    std::vector<float> mxyz((size_t)3 * Nm), dxyz((size_t)3 * Nd), mf, df;
+    std::vector<int32_t> mcol(Nm), dcol(Nd);
+    for (int i = 0; i < Nm; i++) { mxyz[3 * i] = pModel[i].x; mxyz[3 * i + 1] = pModel[i].y; mxyz[3 * i + 2] = pModel[i].z; mcol[i] = pModel[i].c; }
+    for (int i = 0; i < Nd; i++) { dxyz[3 * i] = pData[i].x; dxyz[3 * i + 1] = pData[i].y; dxyz[3 * i + 2] = pData[i].z; dcol[i] = pData[i].c; }
+    const bool need_fpfh = regularizationFPFH > 0;
+    if (need_fpfh) {
+        mf.assign((size_t)GOICP_FPFH_BINS * Nm, 0.f); df.assign((size_t)GOICP_FPFH_BINS * Nd, 0.f);
+        for (int i = 0; i < Nm; i++) for (size_t b = 0; b < pModel[i].cfpfh.size() && b < GOICP_FPFH_BINS; b++) mf[(size_t)GOICP_FPFH_BINS * i + b] = pModel[i].cfpfh[b];
+        for (int i = 0; i < Nd; i++) for (size_t b = 0; b < pData[i].cfpfh.size() && b < GOICP_FPFH_BINS; b++) df[(size_t)GOICP_FPFH_BINS * i + b] = pData[i].cfpfh[b];
+    }
+    goicp_engine_desc d;
+    std::memset(&d, 0, sizeof d);
+    d.S = dt.SIZE; d.xMin = dt.xMin; d.yMin = dt.yMin; d.zMin = dt.zMin; d.scale = dt.scale;
+    d.dt_dist = dt.dist.data();
+    d.nearest_occ = dt.nearest.data(); d.cell_color = dt.cell_color.data(); d.cell_ptr = dt.cell_ptr.data(); d.cell_idx = dt.cell_idx.data();
+    d.Nm = Nm; d.model_xyz = mxyz.data(); d.model_color = mcol.data(); d.model_fpfh = need_fpfh ? mf.data() : nullptr;
+    d.Nd = Nd; d.data_xyz = dxyz.data(); d.data_color = dcol.data(); d.data_fpfh = need_fpfh ? df.data() : nullptr;
+    d.weights = weights.data(); d.maxRotDis = maxRotDis.data();
+    d.inlierNum = inlierNum; d.doTrim = doTrim ? 1 : 0; d.norm = norm; d.cfpfh = cfpfh;
+    d.regularization = regularization; d.regularizationNeighbors = regularizationNeighbors; d.regularizationFPFH = regularizationFPFH;
+    d.device_id = device_id; d.parity_mode = parity_mode;
+    status = goicp_engine_create(&d, &eng_);
+    if (status != GOICP_OK) {
+        eng_ = nullptr;
+        error_message = status == GOICP_ERR_NO_DEVICE ? "no usable HIP device (the MI355X engine has no CPU fallback)" : "goicp_engine_create failed (unsupported configuration)";
+    }
+}
+
+// reference jly_goicp.cpp:890-914 on explicit correspondence lists
+int GoICP::countCompatibilities(const std::vector<int32_t>& idd, const std::vector<int32_t>& idm) const {
+    int bad = 0;
+    for (int i = 0; i < Nd; i++) { const int s = pData[idd[i]].c, t = pModel[idm[i]].c; if (!(known_prop(s) && s == t)) bad++; }
+    return bad;
+}
+
+// reference jly_goicp.cpp:933-946: per-point test on the device, count on the host
+int GoICP::updateCompatibilities() {
+    double R[9], t[3];
+    for (int i = 0; i < 3; i++) { for (int j = 0; j < 3; j++) R[3 * i + j] = optR.val[i][j]; t[i] = optT.val[i][0]; }
+    std::vector<float> dist(Nd); std::vector<int32_t> ok(Nd);
+    status = goicp_engine_point_eval(eng_, R, t, dist.data(), ok.data());
+    int bad = 0;
+    for (int i = 0; i < Nd; i++) if (!ok[i]) bad++;
+    return bad;
+}
+
+// ICP3D<float>::Run (reference jly_icp3d.hpp:197-311): correspondences from the device, the 3x3 algebra here
+float GoICP::icp_run(Matrix& R, Matrix& t) {
+    const int n = Nd;
+    const float err_diff = MSEThresh / 10000;      // jly_goicp.cpp:232
+    int num;
+    if (doTrim) num = (int)(n * (1 - trimFraction)); else num = n;
+    struct Ref { double dis; int id_data, id_model; };
+    std::vector<Ref> pts(n), tmp(n);
+    std::vector<int32_t> ids(n); std::vector<float> dsq(n);
+    std::vector<double> p_m((size_t)3 * std::max(num, 1)), p_d((size_t)3 * std::max(num, 1));
+    double mu_m[3] = {0, 0, 0}, mu_d[3] = {0, 0, 0};
+    double Rd[9], td[3];
+    for (int i = 0; i < 3; i++) { for (int j = 0; j < 3; j++) Rd[3 * i + j] = R.val[i][j]; td[i] = t.val[i][0]; }
+    float err = -1, err_new = 0;
+    stats.icp_calls++;
+    for (size_t iter = 0; iter < 10000; iter++) {
+        stats.icp_iters++;
+        const float r00 = (float)Rd[0], r01 = (float)Rd[1], r02 = (float)Rd[2], r10 = (float)Rd[3], r11 = (float)Rd[4], r12 = (float)Rd[5];
+        const float r20 = (float)Rd[6], r21 = (float)Rd[7], r22 = (float)Rd[8], t0 = (float)td[0], t1 = (float)td[1], t2 = (float)td[2];
+        status = goicp_engine_icp_nn(eng_, Rd, td, ids.data(), dsq.data());
+        if (status != GOICP_OK) return std::numeric_limits<float>::quiet_NaN();
+        err_new = 0;
+        for (int i = 0; i < n; i++) { pts[i].dis = dsq[i]; pts[i].id_data = i; pts[i].id_model = ids[i]; }
+        if (doTrim) {
+            // qsort with a comparator that never reports equality (jly_icp3d.hpp:172-176,254); under glibc's merge
+            // sort ties keep their order, i.e. a stable sort by dis
+            std::stable_sort(pts.begin(), pts.end(), [](const Ref& a, const Ref& b) { return a.dis < b.dis; });
+        }
+        for (int i = 0; i < num; i++) {
+            const int im = pts[i].id_model, id = pts[i].id_data;
+            p_m[3 * i] = pModel[im].x; mu_m[0] += p_m[3 * i];
+            p_m[3 * i + 1] = pModel[im].y; mu_m[1] += p_m[3 * i + 1];
+            p_m[3 * i + 2] = pModel[im].z; mu_m[2] += p_m[3 * i + 2];
+            const float dx = pData[id].x, dy = pData[id].y, dz = pData[id].z;
+            p_d[3 * i] = r00 * dx + r01 * dy + r02 * dz + t0; mu_d[0] += p_d[3 * i];
+            p_d[3 * i + 1] = r10 * dx + r11 * dy + r12 * dz + t1; mu_d[1] += p_d[3 * i + 1];
+            p_d[3 * i + 2] = r20 * dx + r21 * dy + r22 * dz + t2; mu_d[2] += p_d[3 * i + 2];
+            err_new = (float)(err_new + pts[i].dis);
+        }
+        if (err > 0 && err - err_new < err_diff * num) break;
+        err = err_new;
+        // the running means are divided by n (not num) and never reset (jly_icp3d.hpp:260-262,278-279)
+        for (int k = 0; k < 3; k++) { mu_m[k] = mu_m[k] / (double)(float)n; mu_d[k] = mu_d[k] / (double)(float)n; }
+        double H[9];
+        for (int a = 0; a < 3; a++) for (int b = 0; b < 3; b++) {
+            double s = 0;
+            for (int i = 0; i < num; i++) s += (p_d[3 * i + a] - mu_d[a]) * (p_m[3 * i + b] - mu_m[b]);
+            H[3 * a + b] = s;
+        }
+        double Rn[9], Rc[9], tc[3], t_[3];
+        kabsch_rotation(H, Rn);
+        for (int a = 0; a < 3; a++) { double s = 0; for (int k = 0; k < 3; k++) s += Rn[3 * a + k] * mu_d[k]; t_[a] = mu_m[a] - s; }
+        mul3(Rn, Rd, Rc);
+        for (int a = 0; a < 3; a++) { double s = 0; for (int k = 0; k < 3; k++) s += Rn[3 * a + k] * td[k]; tc[a] = s + t_[a]; }
+        std::memcpy(Rd, Rc, sizeof Rc); std::memcpy(td, tc, sizeof tc);
+    }
+    icp_id_data_.resize(n); icp_id_model_.resize(n);
+    for (int i = 0; i < n; i++) { icp_id_data_[i] = pts[i].id_data; icp_id_model_[i] = pts[i].id_model; }
+    for (int i = 0; i < 3; i++) { for (int j = 0; j < 3; j++) R.val[i][j] = Rd[3 * i + j]; t.val[i][0] = td[i]; }
+    return err_new;
+}
+
+// reference jly_goicp.cpp:102-178: DT lookups on the device, sums in the reference's order on the host
+float GoICP::ICP(Matrix& R_icp, Matrix& t_icp) {
+    if (!eng_) return std::numeric_limits<float>::quiet_NaN();
+    icp_run(R_icp, t_icp);
+    if (status != GOICP_OK) return std::numeric_limits<float>::quiet_NaN();
+    double R[9], t[3];
+    for (int i = 0; i < 3; i++) { for (int j = 0; j < 3; j++) R[3 * i + j] = R_icp.val[i][j]; t[i] = t_icp.val[i][0]; }
+    std::vector<float> dist(Nd);
+    status = goicp_engine_point_eval(eng_, R, t, dist.data(), nullptr);
+    if (status != GOICP_OK) return std::numeric_limits<float>::quiet_NaN();
+    int b0 = 0, b1 = 0;
+    if (cfpfh == 1) { b0 = 0; b1 = 41; } else if (cfpfh == 2) { b0 = 0; b1 = 33; } else if (cfpfh == 3) { b0 = 33; b1 = 41; }
+    float error = 0, fpfh = 0;
+    for (int i = 0; i < Nd; i++) {
+        if (!doTrim) {
+            const float dis = weights[i] * dist[i];
+            if (norm == 2) error += dis * dis;
+            if (norm == 1) error += dis;
+        } else minDis_[i] = dist[i];
+        if (cfpfh != 0) {
+            const std::vector<float>& f = pData[icp_id_data_[i]].cfpfh; const std::vector<float>& g = pModel[icp_id_model_[i]].cfpfh;
+            float d = 0;
+            for (int b = b0; b < b1; b++) d += std::fabs((b < (int)f.size() ? f[b] : 0.f) - (b < (int)g.size() ? g[b] : 0.f));
+            fpfh += d;
+        }
+    }
+    fpfh = fpfh / Nd;
+    if (regularization > 0) { const int inc = countCompatibilities(icp_id_data_, icp_id_model_); error += regularization * (inc * inc); }
+    if (regularizationFPFH > 0) error += regularizationFPFH * (fpfh * fpfh);
+    if (doTrim) {
+        intro_select(minDis_.data(), 0, (size_t)(Nd - 1), (size_t)(inlierNum - 1));
+        for (int i = 0; i < inlierNum; i++) error += minDis_[i] * minDis_[i];
+    }
+    return error;
+}
+
+static void axis_angle(float v1, float v2, float v3, float* R) {   // reference jly_goicp.cpp:718-747
+    const float t = std::sqrt(v1 * v1 + v2 * v2 + v3 * v3);
+    if (!(t > 0)) { R[0] = R[4] = R[8] = 1; R[1] = R[2] = R[3] = R[5] = R[6] = R[7] = 0; return; }
+    v1 /= t; v2 /= t; v3 /= t;
+    const float ct = std::cos(t), ct2 = 1 - ct, st = std::sin(t);
+    const float t121 = v1 * v2 * ct2, t122 = v3 * st, t131 = v1 * v3 * ct2, t132 = v2 * st, t231 = v2 * v3 * ct2, t232 = v1 * st;
+    R[0] = ct + v1 * v1 * ct2; R[1] = t121 - t122; R[2] = t131 + t132;
+    R[3] = t121 + t122; R[4] = ct + v2 * v2 * ct2; R[5] = t231 - t232;
+    R[6] = t131 - t132; R[7] = t231 + t232; R[8] = ct + v3 * v3 * ct2;
+}
+
+static goicp_bnb_job make_job(const float* R9, int level, float E, float sse, const TRANSNODE& init) {
+    goicp_bnb_job j;
+    std::memcpy(j.R, R9, sizeof j.R);
+    j.rot_level = level; j.optError_in = E; j.SSEThresh = sse;
+    j.init[0] = init.x; j.init[1] = init.y; j.init[2] = init.z; j.init[3] = init.w; j.init_lb = init.lb;
+    return j;
+}
+
+float GoICP::InnerBnB(const float* R9, int rot_level, TRANSNODE* out) {
+    if (!eng_) return std::numeric_limits<float>::quiet_NaN();
+    goicp_bnb_job j = make_job(R9, rot_level, optError, SSEThresh, initNodeTrans);
+    goicp_bnb_result r;
+    status = goicp_engine_inner_bnb(eng_, &j, &r);
+    stats.inner_calls++; stats.inner_launches++; stats.inner_jobs_launched++; stats.cube_evals += r.cube_evals; stats.trans_pops += r.pops;
+    if (out && r.found) { out->x = r.node[0]; out->y = r.node[1]; out->z = r.node[2]; out->w = r.node[3]; }
+    return r.optErrorT;
+}
+
+// reference jly_goicp.cpp:582-876
+float GoICP::OuterBnB() {
+    RotHeap queueRot;
+    float lb = 0, ub = 0, error;
+    const float nanv = std::numeric_limits<float>::quiet_NaN();
+
+    // initial error (jly_goicp.cpp:602-626): lookups on the device, sum in the reference's order
+    {
+        const double I[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1}, z3[3] = {0, 0, 0};
+        std::vector<float> dist(Nd);
+        status = goicp_engine_point_eval(eng_, I, z3, dist.data(), nullptr);
+        if (status != GOICP_OK) return nanv;
+        for (int i = 0; i < Nd; i++) minDis_[i] = weights[i] * dist[i];
+        if (doTrim) intro_select(minDis_.data(), 0, (size_t)(Nd - 1), (size_t)(inlierNum - 1));
+        optError = 0;
+        for (int i = 0; i < inlierNum; i++) { if (norm == 2) optError += minDis_[i] * minDis_[i]; if (norm == 1) optError += minDis_[i]; }
+        if (regularization > 0) optError += regularization * (Nd * Nd);
+        if (regularizationFPFH > 0) optError += regularizationFPFH * (100 * 8 * 100 * 8);
+        log_error("Init", optError);
+    }
+    Matrix R_icp = optR, t_icp = optT;
+    error = ICP(R_icp, t_icp);
+    if (status != GOICP_OK) return nanv;
+    opt_id_data_ = icp_id_data_; opt_id_model_ = icp_id_model_;         // icp3d.optPoints = icp3d.points (:635)
+    if (error < optError) {
+        optError = error; optR = R_icp; optT = t_icp;
+        optComp = countCompatibilities(opt_id_data_, opt_id_model_);
+        log_error("ICP", error);
+    }
+    queueRot.push(initNodeRot);
+    while (true) {
+        if (queueRot.empty()) break;
+        const ROTNODE par = queueRot.top();
+        queueRot.pop();
+        stats.rot_pops++;
+        if ((optError - par.lb) <= SSEThresh) break;
+        ROTNODE ch[8]; float Rj[8][9]; bool live[8];
+        for (int j = 0; j < 8; j++) {
+            ROTNODE& nd = ch[j];
+            nd.w = par.w / 2; nd.l = par.l + 1;
+            nd.a = par.a + (j & 1) * nd.w; nd.b = par.b + (j >> 1 & 1) * nd.w; nd.c = par.c + (j >> 2 & 1) * nd.w;
+            nd.ub = nd.lb = 0;
+            const float v1 = nd.a + nd.w / 2, v2 = nd.b + nd.w / 2, v3 = nd.c + nd.w / 2;
+            live[j] = !((double)std::sqrt(v1 * v1 + v2 * v2 + v3 * v3) - SQRT3 * nd.w / 2 > PI);      // pi-ball skip (:723)
+            if (live[j]) axis_angle(v1, v2, v3, Rj[j]);
+        }
+        // Speculative batch: the (<=16) InnerBnB calls of this pop are independent searches as long as the incumbent
+        // optError does not change in between, so they are launched together; a result is consumed only if the incumbent
+        // it was computed with is still current, otherwise the rest of the pop is re-launched with the new incumbent.
+        goicp_bnb_result res[16]; float res_E[16]; bool have[16];
+        for (int k = 0; k < 16; k++) have[k] = false;
+        auto launch_from = [&](int first) -> bool {
+            goicp_bnb_job jobs[16]; int slot[16]; int n = 0;
+            for (int k = first; k < 16; k++) {
+                const int j = k >> 1;
+                if (!live[j]) continue;
+                jobs[n] = make_job(Rj[j], (k & 1) ? ch[j].l : -1, optError, SSEThresh, initNodeTrans);
+                slot[n++] = k;
+                if (!speculate) break;
+            }
+            if (n == 0) return true;
+            goicp_bnb_result out[16];
+            status = goicp_engine_inner_bnb_batch(eng_, jobs, n, out);
+            stats.inner_launches++; stats.inner_jobs_launched += n;
+            if (status != GOICP_OK) return false;
+            for (int q = 0; q < n; q++) { res[slot[q]] = out[q]; res_E[slot[q]] = optError; have[slot[q]] = true; }
+            return true;
+        };
+        auto get = [&](int k) -> const goicp_bnb_result* {
+            if (!(have[k] && res_E[k] == optError)) {
+                for (int q = k; q < 16; q++) have[q] = false;
+                if (!launch_from(k)) return nullptr;
+            }
+            stats.inner_calls++; stats.cube_evals += res[k].cube_evals; stats.trans_pops += res[k].pops;
+            return &res[k];
+        };
+        for (int j = 0; j < 8; j++) {
+            if (!live[j]) continue;
+            ROTNODE& nodeRot = ch[j];
+            const goicp_bnb_result* r = get(2 * j);
+            if (!r) return nanv;
+            ub = r->optErrorT;
+            if (ub < optError) {
+                TRANSNODE nodeTrans = optNodeTrans;
+                if (r->found) { nodeTrans.x = r->node[0]; nodeTrans.y = r->node[1]; nodeTrans.z = r->node[2]; nodeTrans.w = r->node[3]; }
+                optError = ub; optNodeRot = nodeRot; optNodeTrans = nodeTrans;
+                for (int a = 0; a < 3; a++) for (int b = 0; b < 3; b++) optR.val[a][b] = Rj[j][3 * a + b];
+                optT.val[0][0] = optNodeTrans.x + optNodeTrans.w / 2;
+                optT.val[1][0] = optNodeTrans.y + optNodeTrans.w / 2;
+                optT.val[2][0] = optNodeTrans.z + optNodeTrans.w / 2;
+                optComp = updateCompatibilities();
+                if (status != GOICP_OK) return nanv;
+                log_error("BNB", optError);
+                R_icp = optR; t_icp = optT;
+                error = ICP(R_icp, t_icp);
+                if (status != GOICP_OK) return nanv;
+                if (error < optError) {
+                    optError = error; optR = R_icp; optT = t_icp;
+                    opt_id_data_ = icp_id_data_; opt_id_model_ = icp_id_model_;
+                    optComp = countCompatibilities(opt_id_data_, opt_id_model_);
+                    log_error("ICP", error);
+                }
+                // drop queued rotation cubes that can no longer win (:843-853)
+                RotHeap q2;
+                while (!queueRot.empty()) { const ROTNODE nd = queueRot.top(); queueRot.pop(); if (nd.lb < optError) q2.push(nd); else break; }
+                queueRot = q2;
+            }
+            r = get(2 * j + 1);
+            if (!r) return nanv;
+            lb = r->optErrorT;
+            if (lb >= optError) continue;
+            nodeRot.ub = ub; nodeRot.lb = lb;
+            queueRot.push(nodeRot);
+        }
+    }
+    return optError;
+}
+
+float GoICP::Register() {
+    trace.clear(); stats = RegisterStats();
+    Initialize();
+    if (!eng_) return std::numeric_limits<float>::quiet_NaN();
+    OuterBnB();
+    double ms = 0; uint64_t ce = 0, lk = 0;
+    goicp_engine_stats(eng_, &ce, &lk, &ms);
+    stats.engine_kernel_ms = ms;
+    Clear();
+    if (status != GOICP_OK) return std::numeric_limits<float>::quiet_NaN();
+    return optError;
+}
+
+}  // namespace goicp

@@ -1,0 +1,76 @@
+/* goicp_c.h -- C wrappers around the host-side GoICP class (go-icp-protein-cavities_amd/csrc/goicp.hpp),
+ * i.e. the registration-level surface of the reference (class GoICP, reference jly_goicp.h:112-218, and the
+ * file pipeline of its main(), reference jly_main.cpp:54-179), for language bindings (ctypes, cgo, ...).
+ * The hot path itself is include/goicp_engine.h. No torch / C++ types cross this boundary.
+ */
+#ifndef GOICP_C_H
+#define GOICP_C_H
+#include <stdint.h>
+#include "goicp_engine.h"
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct goicp_handle goicp_handle;
+
+goicp_handle* goicp_new(void);
+void goicp_free(goicp_handle*);
+
+/* cfg[18]: MSEThresh, rotMinX, rotMinY, rotMinZ, rotWidth, transMinX, transMinY, transMinZ, transWidth, trimFraction,
+ * regularization, regularizationNeighbors, regularizationFPFH, cfpfh, norm, ponderation, distTransSize,
+ * distTransExpandFactor  -- the keys readConfig() reads (reference jly_main.cpp:236-264), values as parsed by atof */
+int goicp_set_config(goicp_handle*, const double* cfg18);
+int goicp_read_config(goicp_handle*, const char* path);         /* config.txt syntax of reference ConfigMap.cpp:17-60 */
+int goicp_get_config(goicp_handle*, double* cfg18);
+int goicp_set_options(goicp_handle*, int device_id, int parity_mode, int speculate, int verbose);
+int goicp_set_clouds(goicp_handle*, int Nm, const float* mxyz, const int32_t* mcol, const float* mfpfh,
+                     int Nd, const float* dxyz, const int32_t* dcol, const float* dfpfh);
+int goicp_set_nd(goicp_handle*, int Nd);                        /* goicp.Nd = NdDownsampled, reference jly_main.cpp:114-117 */
+
+int goicp_build_dt(goicp_handle*);                              /* GoICP::BuildDT */
+/* adopt externally built tables instead (geom4 = xMin,yMin,zMin,scale; nearest = linear cell index) */
+int goicp_load_dt(goicp_handle*, int S, const double* geom4, const float* dist, const int32_t* nearest,
+                  const int32_t* cell_color, const int32_t* cell_ptr, const int32_t* cell_idx);
+int goicp_dt_geom(goicp_handle*, double* geom8);                /* xMin,xMax,yMin,yMax,zMin,zMax,scale,SIZE */
+int goicp_dt_dump(goicp_handle*, float* dist, int32_t* nearest, int32_t* cell_color);
+
+int goicp_initialize(goicp_handle*);                            /* GoICP::Initialize + engine creation; GOICP_* status */
+goicp_engine* goicp_get_engine(goicp_handle*);                  /* valid between goicp_initialize and goicp_clear/register */
+void goicp_clear(goicp_handle*);
+int goicp_get_weights(goicp_handle*, float* w);                 /* [Nd] */
+int goicp_get_maxrotdis(goicp_handle*, float* m);               /* [20*Nd] */
+int goicp_inlier_num(goicp_handle*);
+float goicp_sse_thresh(goicp_handle*);
+void goicp_set_opt_error(goicp_handle*, float e);
+void goicp_set_init_trans(goicp_handle*, float x, float y, float z, float w, float lb);
+
+/* GoICP::ICP (reference jly_goicp.cpp:102-178); R9/t3 in-out; corr[Nd*2]=(id_data,id_model) or NULL */
+float goicp_icp(goicp_handle*, double* R9, double* t3, int32_t* corr);
+/* GoICP::Register. out16: optR[9], optT[3], optError, optComp, Nd, inlierNum. Returns optError (NaN on failure). */
+float goicp_register(goicp_handle*, double* out16);
+int goicp_status(goicp_handle*);
+const char* goicp_error_message(goicp_handle*);
+/* trace of "Error*:" lines: tags[i] in {0:Init,1:ICP,2:BNB}; returns count */
+int goicp_get_trace(goicp_handle*, int32_t* tags, float* values, int cap);
+/* stats8: rot_pops, inner_calls, inner_launches, inner_jobs_launched, cube_evals, trans_pops, icp_calls, icp_iters */
+int goicp_get_stats(goicp_handle*, uint64_t* stats8, double* engine_kernel_ms);
+
+/* ---- file pipeline of the reference's main() (jly_main.cpp:54-179) ------------------------------------
+ * argv semantics: <TARGET mol2> <SOURCE mol2> <Nd downsample> <CONFIG> <OUTPUT> <PAIR#>; reads cfpfh/<name>.cfpfh next to
+ * `base_dir` (the directory that holds cavities/ cfpfh/ cavitiesN/), writes cavitiesN/<name>_sim<k>N.xyz, <OUTPUT>
+ * and <OUTPUT stem>_rescaled.txt. result24: R[9], t[3], error, compat, Nd, seconds(register), seconds(DT),
+ * rescaled t[3], cube_evals, trans_pops, rot_pops, status. */
+int goicp_run_pair_files(const char* base_dir, const char* target_mol2, const char* source_mol2, int nd_downsampled,
+                         const char* config_path, const char* output_path, int pair, int device_id, int verbose,
+                         double* result24);
+/* demo clouds: "N\n x y z\n..." text files (reference demo/model_bunny.txt), no colours / c-FPFH */
+int goicp_run_txt_files(const char* model_txt, const char* data_txt, int nd_downsampled, const char* config_path,
+                        const char* output_path, int device_id, int verbose, double* result24);
+/* Transformation::computeRMSD (reference transformation.cpp:453-464) and applyTransformationProtein (:469-539) */
+float goicp_compute_rmsd(const char* aligned_mol2, const char* rot_mol2);
+int goicp_apply_transformation_protein(const char* output_txt, const char* protein_mol2, const char* out_mol2);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,134 @@
+/* goicp_engine.h -- C ABI of the MI355X (gfx950) Go-ICP inner-BnB error-evaluation engine.
+ *
+ * Drop-in boundary: the reference has no FFI layer; its seam is the C++ class GoICP
+ * (reference jly_goicp.h:112-218).  Each entry point below replaces one private seam of that class:
+ *
+ *   goicp_engine_create        <- the device-side copy of what GoICP::BuildDT() (jly_goicp.cpp:79-99) and
+ *                                 GoICP::Initialize() (jly_goicp.cpp:180-267) leave behind: DT grid + cell
+ *                                 tables (jly_3ddt.h:64-139), weights[], maxRotDis[][], inlierNum, flags
+ *   goicp_engine_set_rotation  <- pDataTemp = R*pData                         (jly_goicp.cpp:750-756)
+ *   goicp_engine_eval_cubes    <- the per-cube sweep of GoICP::InnerBnB       (jly_goicp.cpp:322-550):
+ *                                 DT3D::Distance (jly_3ddt.cpp:1139-1191) per point, clamp, trim
+ *                                 (intro_select, jly_sorting.hpp:229), ub/lb sums, corner penalty terms
+ *                                 (checkCompatibilities jly_goicp.cpp:919, sumFPFH jly_goicp.cpp:1689)
+ *   goicp_engine_inner_bnb*    <- float GoICP::InnerBnB(float*, TRANSNODE*)   (jly_goicp.cpp:286-579),
+ *                                 called from OuterBnB at jly_goicp.cpp:768 and :861
+ *   goicp_engine_point_eval    <- the Nd DT lookups of the initial error (jly_goicp.cpp:602-605), of
+ *                                 GoICP::ICP's error step (jly_goicp.cpp:117-137) and the per-point
+ *                                 compatibility test of updateCompatibilities (jly_goicp.cpp:933-946)
+ *   goicp_engine_icp_nn        <- the 1-NN correspondence search of ICP3D<float>::Run
+ *                                 (jly_icp3d.hpp:236-250; nanoflann kd-tree replaced by exhaustive search)
+ *
+ * Conventions: every call returns a GOICP_* status (never exits the process); the caller owns all host
+ * buffers; a handle is bound to one GPU and one HIP stream and is not thread-safe; distinct handles are
+ * independent.  All pointers are plain host pointers unless the name ends in _dev.
+ * There is no CPU fallback: without a usable HIP device goicp_engine_create fails with GOICP_ERR_NO_DEVICE.
+ */
+#ifndef GOICP_ENGINE_H
+#define GOICP_ENGINE_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GOICP_OK               0
+#define GOICP_ERR_ARG          1   /* bad argument / unsupported configuration */
+#define GOICP_ERR_NO_DEVICE    2   /* no HIP device, or HIP runtime failure at create */
+#define GOICP_ERR_HIP          3   /* HIP runtime error (see goicp_engine_last_error) */
+#define GOICP_ERR_OVERFLOW     4   /* device queue capacity exceeded even after regrowth */
+#define GOICP_ERR_LIMIT        5   /* max_pops safety bound reached */
+
+#define GOICP_MAXROTLEVEL 20       /* jly_goicp.h:95 */
+#define GOICP_FPFH_BINS   41       /* jly_main.cpp:301 */
+
+typedef struct goicp_engine goicp_engine;
+
+typedef struct goicp_engine_desc {
+    /* distance transform (DT3D, jly_3ddt.h:112-139): float distance per cell, x fastest */
+    int32_t S;
+    double xMin, yMin, zMin, scale;
+    const float*   dt_dist;        /* [S^3] */
+    /* cell tables for the penalty terms; all NULL when both regularization and regularizationFPFH are 0 */
+    const int32_t* nearest_occ;    /* [S^3] linear index (z*S+y)*S+x of the nearest occupied cell (emptyCells) */
+    const int32_t* cell_color;     /* [S^3] -2 unoccupied, -1 mixed, else property code (cellPoints[].c) */
+    const int32_t* cell_ptr;       /* [S^3+1] CSR offsets into cell_idx (cellPoints[].points) */
+    const int32_t* cell_idx;       /* [cell_ptr[S^3]] model point ids */
+    /* clouds */
+    int32_t Nm;
+    const float*   model_xyz;      /* [Nm*3] */
+    const int32_t* model_color;    /* [Nm] or NULL */
+    const float*   model_fpfh;     /* [Nm*41] or NULL */
+    int32_t Nd;
+    const float*   data_xyz;       /* [Nd*3] */
+    const int32_t* data_color;     /* [Nd] or NULL */
+    const float*   data_fpfh;      /* [Nd*41] or NULL */
+    /* Initialize() products */
+    const float*   weights;        /* [Nd] */
+    const float*   maxRotDis;      /* [20*Nd] */
+    int32_t inlierNum;
+    int32_t doTrim;
+    int32_t norm;                  /* 1 or 2 */
+    int32_t cfpfh;                 /* 0 / 1 (41 bins) / 2 (33) / 3 (8 colour bins) */
+    float   regularization;
+    float   regularizationNeighbors;   /* must be 0 (direct-neighbour penalty is out of scope) */
+    float   regularizationFPFH;
+    int32_t device_id;
+    /* 1: ub/lb summed in the reference's order (float, sequential over points; bit-exact for untrimmed
+     *    runs; used when Nd <= 1536, else falls back to 0).  0: fp64 tree reduction (order-free; within n*eps of the reference). */
+    int32_t parity_mode;
+} goicp_engine_desc;
+
+typedef struct goicp_bnb_job {
+    float   R[9];          /* rotation applied to the data cloud before the search (row-major) */
+    int32_t rot_level;     /* >=0: subtract maxRotDis[rot_level][i]; -1: no rotation uncertainty (ub call) */
+    float   optError_in;   /* incumbent at entry (optErrorT = optError, jly_goicp.cpp:297) */
+    float   SSEThresh;
+    float   init[4];       /* initNodeTrans x,y,z,w */
+    float   init_lb;       /* initNodeTrans.lb (0 in the reference) */
+} goicp_bnb_job;
+
+typedef struct goicp_bnb_result {
+    float    optErrorT;    /* return value of InnerBnB */
+    float    node[4];      /* best cube x,y,z,w (valid when found != 0) */
+    int32_t  found;        /* some cube improved on optError_in */
+    int32_t  status;       /* GOICP_OK / GOICP_ERR_OVERFLOW / GOICP_ERR_LIMIT */
+    uint32_t pops;         /* queue pops */
+    uint32_t cube_evals;   /* cubes evaluated (8 per expanded node) */
+} goicp_bnb_result;
+
+int  goicp_engine_create(const goicp_engine_desc* desc, goicp_engine** out);
+void goicp_engine_destroy(goicp_engine* h);
+const char* goicp_engine_last_error(const goicp_engine* h);
+
+/* number of rotation slots for eval_cubes (each holds one rotated copy of the data cloud on the device) */
+int goicp_engine_set_rotation(goicp_engine* h, int slot, const float* R9);
+int goicp_engine_num_slots(const goicp_engine* h);
+
+/* (cube) -> (ub, lb) for n cubes given as x,y,z,w quadruples, rotation slot `slot`, rot_level as in the job */
+int goicp_engine_eval_cubes(goicp_engine* h, int slot, int rot_level, const float* cubes, int n, float* ub, float* lb);
+/* same on device-resident buffers, asynchronous on the engine's stream (bench / pipelines) */
+int goicp_engine_eval_cubes_dev(goicp_engine* h, int slot, int rot_level, const void* cubes_dev, int n, void* ub_dev, void* lb_dev);
+/* per-lattice-point penalty terms at n translations (x,y,z triplets): incompatibility counts and c-FPFH means */
+int goicp_engine_corner_terms(goicp_engine* h, int slot, const float* xyz, int n, int32_t* incompat, float* fpfh);
+
+/* reference-order best-first translation search, fully device-resident; jobs run concurrently */
+int goicp_engine_inner_bnb(goicp_engine* h, const goicp_bnb_job* job, goicp_bnb_result* result);
+int goicp_engine_inner_bnb_batch(goicp_engine* h, const goicp_bnb_job* jobs, int njobs, goicp_bnb_result* results);
+
+/* q_i = (float)(R*p_i + t) (double R,t); dist[i] = DT(q_i) (unweighted); compat[i] = 1/0 (may be NULL) */
+int goicp_engine_point_eval(goicp_engine* h, const double* R9, const double* t3, float* dist, int32_t* compat);
+/* q_i = R*p_i + t in float (R,t rounded from double); nearest model point id and squared distance */
+int goicp_engine_icp_nn(goicp_engine* h, const double* R9, const double* t3, int32_t* id_model, float* dist_sq);
+
+int goicp_engine_synchronize(goicp_engine* h);
+/* cumulative counters since create: cube evaluations, point lookups, kernel milliseconds (HIP events) */
+int goicp_engine_stats(const goicp_engine* h, uint64_t* cube_evals, uint64_t* lookups, double* kernel_ms);
+/* opaque hipStream_t of the handle, for callers that time with their own HIP events */
+void* goicp_engine_stream(const goicp_engine* h);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,231 @@
+"""GPU (-m gpu): the HIP path, called through the C ABI (include/goicp_engine.h, include/goicp_c.h), against
+(a) the committed known answers produced by the compiled reference (tests/golden/) and
+(b) the plain-C oracle on seeded inputs.
+Tolerances: untrimmed runs use parity_mode=1 (reference summation order) and must be BIT-EXACT; trimmed sums
+are accumulated in fp64 and must agree to 1e-5 relative (north_star tolerance); R,t to 1e-5 absolute."""
+import os
+
+import numpy as np
+import pytest
+
+import goicp_amd
+from oracle.refbind import cfg_vector
+from helpers import GOLDEN, load_clouds, load_hotpath, load_register, rot_cloud, oracle_for, synth_pair
+
+pytestmark = pytest.mark.gpu
+RTOL = 1e-5
+
+
+def lin(near3, S):
+    return (near3[:, 2].astype(np.int64) * S + near3[:, 1]) * S + near3[:, 0]
+
+
+def engine_from_hotpath(H, P, parity=1):
+    cfg = H["cfg"]; S = int(H["geom"][7])
+    g4 = (H["geom"][0], H["geom"][2], H["geom"][4], H["geom"][6])
+    do_trim = float(np.float32(cfg[9])) >= 0.001
+    return goicp_amd.Engine(S=S, geom4=g4, dist=H["dist"], data_xyz=P["s"], weights=H["weights"], maxrotdis=H["maxrotdis"],
+                            model_xyz=P["t"], inlier_num=int(H["inlierNum"]), do_trim=do_trim, norm=int(cfg[14]), cfpfh=int(cfg[13]),
+                            reg=float(np.float32(cfg[10])), reg_fpfh=float(np.float32(cfg[12])), nearest=lin(H["nearest3"], S),
+                            cell_color=H["cellc"], cell_ptr=H["cell_ptr"], cell_idx=H["cell_idx"], model_color=P["tc"], data_color=P["sc"],
+                            model_fpfh=P["tf"], data_fpfh=P["sf"], parity_mode=parity)
+
+
+HOT = ["pair1_default", "pair1_trim", "pair1_fpfh", "pair1_norm1", "pair2_S50"]
+
+
+def close(a, b, exact):
+    a = np.asarray(a, np.float32); b = np.asarray(b, np.float32)
+    if exact:
+        return np.array_equal(a, b)
+    return np.allclose(a, b, rtol=RTOL, atol=1e-7)
+
+
+@pytest.mark.parametrize("name", HOT)
+def test_eval_cubes_against_reference_tables(name):
+    H = load_hotpath(name); P = load_clouds("pair2" if name.startswith("pair2") else "pair1")
+    exact = "trim" not in name
+    e = engine_from_hotpath(H, P)
+    cubes = H["cubes"]
+    for k in range(len(H["call_level"])):
+        rows = cubes[cubes[:, 0] == k]
+        if not len(rows):
+            continue
+        e.set_rotation(k % 16, H["call_R"][k])
+        ub, lb = e.eval_cubes(k % 16, int(H["call_level"][k]), rows[:, 1:5])
+        assert close(ub, rows[:, 5], exact), (name, k, np.abs(ub - rows[:, 5]).max())
+        assert close(lb, rows[:, 6], exact), (name, k, np.abs(lb - rows[:, 6]).max())
+    e.close()
+
+
+@pytest.mark.parametrize("name", ["pair1_default", "pair1_fpfh", "pair2_S50"])
+def test_corner_terms_against_reference(name):
+    H = load_hotpath(name); P = load_clouds("pair2" if name.startswith("pair2") else "pair1")
+    e = engine_from_hotpath(H, P)
+    for row in H["corners"]:
+        k = int(row[0])
+        e.set_rotation(0, H["call_R"][k])
+        cnt, fp = e.corner_terms(0, row[1:4])
+        assert cnt[0] == int(row[4])
+        if int(H["cfg"][13]) != 0:
+            assert fp[0] == np.float32(row[5])          # float mean in the reference's summation order
+    e.close()
+
+
+@pytest.mark.parametrize("name", HOT)
+def test_inner_bnb_against_reference(name):
+    H = load_hotpath(name); P = load_clouds("pair2" if name.startswith("pair2") else "pair1")
+    exact = "trim" not in name
+    e = engine_from_hotpath(H, P)
+    cfg = H["cfg"]
+    init = tuple(np.float32(cfg[5:9]))
+    jobs = [dict(R=H["call_R"][k], level=int(H["call_level"][k]), E=H["call_E"][k], sse=np.float32(H["sse"]), init=init)
+            for k in range(len(H["call_level"]))]
+    res = e.inner_bnb_batch(jobs)          # all jobs of the fixture in ONE launch
+    for k, r in enumerate(res):
+        assert r["status"] == 0
+        assert close(r["val"], H["call_val"][k], exact), (name, k, r["val"], H["call_val"][k])
+        if r["found"]:
+            assert np.array_equal(r["node"], H["call_node"][k]), (name, k)
+        else:
+            assert r["val"] == H["call_E"][k]
+    e.close()
+
+
+def test_point_eval_and_icp_nn_against_oracle():
+    H = load_hotpath("pair1_default"); P = load_clouds("pair1")
+    e = engine_from_hotpath(H, P)
+    o = oracle_for(P, H["cfg"], H); o.initialize()
+    rng = np.random.default_rng(5)
+    for _ in range(5):
+        aa = rng.uniform(-1, 1, 3); th = np.linalg.norm(aa); k = aa / th
+        K = np.array([[0, -k[2], k[1]], [k[2], 0, -k[0]], [-k[1], k[0], 0]])
+        R = np.eye(3) + np.sin(th) * K + (1 - np.cos(th)) * K @ K
+        t = rng.uniform(-0.3, 0.3, 3)
+        dist, ok = e.point_eval(R, t)
+        s = P["s"].astype(np.float32)
+        q = np.stack([(R[a, 0] * s[:, 0].astype(np.float64) + R[a, 1] * s[:, 1] + R[a, 2] * s[:, 2] + t[a]).astype(np.float32) for a in range(3)], 1)
+        assert np.array_equal(dist, o.distance(q.astype(np.float64)))
+        ids, d = e.icp_nn(R, t)
+        Rf = R.astype(np.float32); tf = t.astype(np.float32)
+        qf = np.stack([((Rf[a, 0] * s[:, 0] + Rf[a, 1] * s[:, 1]) + Rf[a, 2] * s[:, 2]) + tf[a] for a in range(3)], 1).astype(np.float32)
+        m = P["t"].astype(np.float32)
+        dd = qf[:, None, :] - m[None, :, :]
+        d2 = ((dd[..., 0] * dd[..., 0] + dd[..., 1] * dd[..., 1]) + dd[..., 2] * dd[..., 2]).astype(np.float32)
+        assert np.array_equal(ids, d2.argmin(1)) and np.array_equal(d, d2.min(1))
+    e.close()
+
+
+REG = ["pair1_default", "pair1_fpfh", "pair1_fpfh33", "pair1_color8", "pair1_norm1", "pair1_trim", "pair1_S50", "pair1_S100_geo"]
+
+
+@pytest.mark.parametrize("name", REG)
+def test_register_against_reference_known_answers(name):
+    """Whole GoICP::Register() on the GPU path vs the compiled reference's R, t, error, compat and Error* trace."""
+    G = load_register()[name]; P = load_clouds("pair1")
+    g = goicp_amd.GoICP(cfg_vector(**G["cfg"])[0])
+    g.set_clouds(P["t"], P["s"], P["tc"], P["sc"], P["tf"], P["sf"])
+    g.build_dt()
+    out = g.register()
+    exact = "trim" not in name
+    assert np.abs(out["R"] - np.array(G["R"])).max() < 1e-5 and np.abs(out["t"] - np.array(G["t"])).max() < 1e-5
+    assert out["comp"] == G["comp"]
+    if exact:
+        assert float(out["error"]) == G["error"]
+        assert [(a, float("%g" % b)) for a, b in out["trace"]] == [tuple(x) for x in G["trace"]]
+    else:
+        assert abs(float(out["error"]) - G["error"]) <= RTOL * G["error"]
+    g.close()
+
+
+def test_register_pair2_default_known_answer():
+    # 2.6 M cube evaluations in the reference (35 s on one CPU core); SURVEY.md 8(c): Error 16.1742, Compatibilities 118
+    G = load_register()["pair2_default"]; P = load_clouds("pair2")
+    g = goicp_amd.GoICP(cfg_vector(**G["cfg"])[0])
+    g.set_clouds(P["t"], P["s"], P["tc"], P["sc"], P["tf"], P["sf"])
+    g.build_dt()
+    out = g.register()
+    assert float(out["error"]) == G["error"] and out["comp"] == G["comp"]
+    assert np.abs(out["R"] - np.array(G["R"])).max() < 1e-5 and np.abs(out["t"] - np.array(G["t"])).max() < 1e-5
+    assert out["stats"]["cube_evals"] == 2610832
+    g.close()
+
+
+def test_speculative_batching_does_not_change_the_result():
+    G = load_register()["pair1_fpfh33"]; P = load_clouds("pair1")
+    outs = []
+    for spec in (0, 1):
+        g = goicp_amd.GoICP(cfg_vector(**G["cfg"])[0], speculate=spec)
+        g.set_clouds(P["t"], P["s"], P["tc"], P["sc"], P["tf"], P["sf"]); g.build_dt()
+        outs.append(g.register()); g.close()
+    assert np.array_equal(outs[0]["R"], outs[1]["R"]) and np.array_equal(outs[0]["t"], outs[1]["t"]) and outs[0]["error"] == outs[1]["error"]
+    assert outs[0]["trace"] == outs[1]["trace"]
+    assert outs[1]["stats"]["inner_launches"] < outs[0]["stats"]["inner_launches"]
+
+
+@pytest.mark.parametrize("n,S,trim", [(1000, 100, 0.0), (1000, 100, 0.1), (5000, 100, 0.1), (3000, 60, 0.0)])
+def test_synthetic_cloud_against_oracle(n, S, trim):
+    """Seeded synthetic pair (SURVEY.md 8(d) generator), geometric path: cube tables + InnerBnB vs the oracle."""
+    P = synth_pair(n, seed=20260101 + n)
+    v, _ = cfg_vector(distTransSize=S, trimFraction=trim, regularization=0.0, ponderation=0, MSEThresh=0.001)
+    o = oracle_for(P, v); o.initialize()
+    dist, near3, cc, _ = o.dt_dump()
+    e = goicp_amd.Engine(S=S, geom4=(o.geom[0], o.geom[2], o.geom[4], o.geom[6]), dist=dist, data_xyz=P["s"], weights=o.weights(),
+                         maxrotdis=o.maxrotdis(), model_xyz=P["t"], inlier_num=o.inlier_num(), do_trim=trim >= 0.001, norm=2, parity_mode=1)
+    rng = np.random.default_rng(n + S)
+    exact = trim < 0.001 and n <= 1536
+    for it in range(3):
+        R = o.axis_angle(rng.uniform(-2, 2, 3).astype(np.float32))
+        o.rotate(R); e.set_rotation(it, R)
+        lvl = int(rng.integers(-1, 4))
+        cubes = []
+        for L in (1, 2, 3, 4):
+            w = np.float32(1.0 / 2 ** L)
+            ijk = rng.integers(0, 2 ** L, (12, 3))
+            for a in ijk:
+                cubes.append([np.float32(-0.5) + a[0] * w, np.float32(-0.5) + a[1] * w, np.float32(-0.5) + a[2] * w, w])
+        cubes = np.array(cubes, np.float32)
+        ub, lb = e.eval_cubes(it, lvl, cubes)
+        oub, olb = o.eval_cubes(lvl, cubes)
+        assert close(ub, oub, exact) and close(lb, olb, exact), (np.abs(ub - oub).max(), np.abs(lb - olb).max())
+        E = np.float32(oub.min() * 1.5)
+        o.set_opt_error(E)
+        val, node = o.inner_bnb(lvl)
+        r = e.inner_bnb(R=R, level=lvl, E=E, sse=np.float32(o.sse_thresh()), init=(-0.5, -0.5, -0.5, 1.0))
+        assert r["status"] == 0
+        assert close(r["val"], val, exact), (r["val"], val)
+        if exact:
+            assert np.array_equal(r["node"], node[:4]) or not r["found"]
+    e.close()
+
+
+def test_full_size_properties_300_cubed():
+    """BASELINE config-3 shape (N=5000, 300^3 DT, trim 0.1): size-independent properties of the cube sweep.
+    (i) a cube evaluated alone == the same cube inside a large batch; (ii) lb <= ub; (iii) bounds are monotone in
+    the rotation-uncertainty level (larger rho => smaller residuals); (iv) ub of a zero-width cube == the
+    point_eval residual sum at that translation."""
+    n, S = 5000, 300
+    P = synth_pair(n)
+    import time
+    g = goicp_amd.GoICP(cfg_vector(distTransSize=S, trimFraction=0.1, regularization=0.0, ponderation=0, MSEThresh=0.001)[0])
+    g.set_clouds(P["t"], P["s"]); g.build_dt(); g.initialize()
+    e = g.engine()
+    R = np.eye(3, dtype=np.float32)
+    e.set_rotation(0, R)
+    rng = np.random.default_rng(1)
+    w = np.float32(1 / 16)
+    ijk = rng.integers(0, 16, (512, 3))
+    cubes = np.concatenate([np.float32(-0.5) + ijk * w, np.full((512, 1), w)], 1).astype(np.float32)
+    ub, lb = e.eval_cubes(0, -1, cubes)
+    ub1, lb1 = e.eval_cubes(0, -1, cubes[37:38])
+    assert ub1[0] == ub[37] and lb1[0] == lb[37]
+    assert np.all(lb <= ub)
+    ub3, lb3 = e.eval_cubes(0, 3, cubes); ub6, lb6 = e.eval_cubes(0, 6, cubes)
+    assert np.all(ub3 <= ub6 + 1e-6) and np.all(ub6 <= ub + 1e-6)
+    z = np.array([[0.03125, -0.0625, 0.015625, 0.0]], np.float32)
+    ubz, lbz = e.eval_cubes(0, -1, z)
+    d, _ = e.point_eval(np.eye(3), z[0, :3].astype(np.float64), want_compat=False)
+    k = g.inlier_num()
+    ref = np.sort(d.astype(np.float64) ** 2)[:k].sum()
+    assert abs(ubz[0] - ref) <= 1e-5 * ref and abs(lbz[0] - ubz[0]) <= 1e-6 * ref
+    g.close()
