@@ -1,0 +1,236 @@
+#!/usr/bin/env python3
+"""bench.py -- translation-BnB cube-evaluations/s (+ end-to-end pair registrations/s) on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+
+Workload (BASELINE.json configs[2], the one the metric is quoted on): seeded synthetic 5 000-point shell cloud vs a
+rotated + noised copy with 10 % outliers, trimFraction 0.1, 300^3 distance transform, MSEThresh 1e-3, penalties off.
+One "step" = one launch group of the cube sweep: 16 rotations x 2 bound variants (rho = 0 and rho = maxRotDis[3]) x all
+4 680 cubes of octree levels 1-4 of [-0.5,0.5]^3 = 149 760 cube evaluations, every input resident in HBM beforehand.
+Per rank the work is fixed (weak scaling): pairs are independent, there is no data-path collective.
+The same run also registers the pair end to end (Register(), and BuildDT()+Register()) and, on rank 0 at N=1, times
+the CPU reference (oracle/_ref, the unmodified reference compiled in place) on a bounded replay of the same searches.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+N_POINTS = 5000
+DT_SIZE = 300
+TRIM = 0.1
+N_ROT = 16
+PEAK_HBM_GBPS = 8000.0          # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
+TILE_CUBES = 8                  # cubes that share one register-resident copy of the cloud (TC in engine.hip)
+
+
+def level_cubes():
+    rows = []
+    for L in (1, 2, 3, 4):
+        n = 2 ** L; w = np.float32(1.0 / n)
+        for k in range(n):
+            for j in range(n):
+                for i in range(n):          # x fastest: adjacent cubes of a tile are x-neighbours
+                    rows.append((np.float32(-0.5) + i * w, np.float32(-0.5) + j * w, np.float32(-0.5) + k * w, w))
+    return np.array(rows, np.float32)
+
+
+def algorithmic_bytes_per_cube_eval(nd):
+    # Nd x 4 B (one fp32 DT value per point) + 8 B (ub, lb) + Nd x 20 B / T (xyz + weight + rho per tile)
+    return nd * 4 + 8 + nd * 20 / TILE_CUBES
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--points", type=int, default=N_POINTS)
+    ap.add_argument("--dt", type=int, default=DT_SIZE)
+    ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
+    ap.add_argument("--no-register", action="store_true", help="skip the end-to-end registration leg")
+    ap.add_argument("--cpu-seconds", type=float, default=15.0)
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    rank = int(os.environ.get("RANK", "0")); world = int(os.environ.get("WORLD_SIZE", "1")); local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl")       # RCCL on ROCm
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+
+    import goicp_amd
+    from helpers import synth_pair
+    goicp_amd.load_library()                  # fails loudly if the HIP extension is missing
+
+    nd = args.points
+    P = synth_pair(nd, seed=20260101, theta_range=(2.2, 3.1))
+    cfg = goicp_amd.cfg_vector(MSEThresh=0.001, trimFraction=TRIM, regularization=0.0, regularizationFPFH=0.0, cfpfh=0,
+                               ponderation=0, norm=2, distTransSize=args.dt)
+    g = goicp_amd.GoICP(cfg, device_id=local)
+    g.set_clouds(P["t"], P["s"])
+    t0 = time.time(); g.build_dt(); t_dt = time.time() - t0
+    g.initialize()
+    eng = g.engine()
+
+    # ---- micro-batch inputs, resident in HBM before the timed region ------------------------------------
+    rng = np.random.default_rng(20260102)
+    rots = []
+    for _ in range(N_ROT):
+        aa = rng.normal(size=3); aa = aa / np.linalg.norm(aa) * rng.uniform(0, np.pi)
+        th = np.linalg.norm(aa); k = aa / th
+        K = np.array([[0, -k[2], k[1]], [k[2], 0, -k[0]], [-k[1], k[0], 0]])
+        rots.append((np.eye(3) + np.sin(th) * K + (1 - np.cos(th)) * K @ K).astype(np.float32))
+    for s, R in enumerate(rots):
+        eng.set_rotation(s, R)
+    cubes_h = level_cubes()
+    ncube = len(cubes_h)
+    cubes = torch.from_numpy(cubes_h).to(dev)
+    ub = torch.empty((N_ROT * 2, ncube), dtype=torch.float32, device=dev); lb = torch.empty_like(ub)
+    torch.cuda.synchronize()
+    stream = torch.cuda.ExternalStream(eng.stream(), device=dev)     # the engine's own HIP stream
+
+    def step():
+        for s in range(N_ROT):
+            for v, lvl in enumerate((-1, 3)):
+                q = 2 * s + v
+                eng.eval_cubes_dev(s, lvl, cubes.data_ptr(), ncube, ub[q].data_ptr(), lb[q].data_ptr())
+
+    for _ in range(args.warmup):
+        step()
+    eng.synchronize()
+    ev0 = torch.cuda.Event(enable_timing=True); ev1 = torch.cuda.Event(enable_timing=True)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    with torch.cuda.stream(stream):
+        ev0.record(stream)
+    for _ in range(args.steps):
+        step()
+    with torch.cuda.stream(stream):
+        ev1.record(stream)
+    eng.synchronize(); torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    ev_ms = ev0.elapsed_time(ev1)
+    if world > 1:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+    evals_per_step = N_ROT * 2 * ncube
+    value = world * evals_per_step * args.steps / elapsed
+    launches = args.steps * N_ROT * 2
+    kern_ms = ev_ms / launches
+    bytes_per_launch = algorithmic_bytes_per_cube_eval(nd) * ncube
+    achieved = bytes_per_launch / (kern_ms * 1e-3) / 1e9
+    # sanity: a finite checksum of the outputs (work was really done)
+    checksum = float(ub.double().sum().item() + lb.double().sum().item())
+    assert np.isfinite(checksum)
+
+    # ---- end-to-end registration of the same pair ------------------------------------------------------
+    reg = None
+    if not args.no_register:
+        g.clear()
+        g.record_jobs(True)
+        if world > 1:
+            dist.barrier()
+        t0 = time.perf_counter(); out = g.register(); t_reg = time.perf_counter() - t0
+        if world > 1:
+            tt = torch.tensor([t_reg], dtype=torch.float64, device=dev); dist.all_reduce(tt, op=dist.ReduceOp.MAX); t_reg_max = float(tt.item())
+        else:
+            t_reg_max = t_reg
+        reg = dict(register_seconds=t_reg_max, dt_build_seconds=t_dt, pair_registrations_per_sec=world / t_reg_max,
+                   pair_registrations_per_sec_incl_dt_build=world / (t_reg_max + t_dt), error=float(out["error"]),
+                   cube_evals=out["stats"]["cube_evals"], rot_pops=out["stats"]["rot_pops"], inner_calls=out["stats"]["inner_calls"],
+                   inner_launches=out["stats"]["inner_launches"], engine_kernel_ms=out["kernel_ms"],
+                   dR_vs_planted=float(np.abs(out["R"] - P["Rtrue"]).max()), dt_vs_planted=float(np.abs(out["t"] - P["ttrue"]).max()))
+
+    # ---- CPU baseline: the unmodified reference (oracle/_ref) replaying the same InnerBnB calls, bounded -------
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu:
+        cpu = cpu_baseline(g, P, cfg, args, reg)
+
+    # the DT / engine can go now
+    g.close()
+
+    if rank == 0:
+        traffic = None
+        pj = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
+        if os.path.exists(pj):
+            try:
+                traffic = json.load(open(pj)).get("hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        line = {
+            "metric": "translation_bnb_cube_evals_per_sec", "value": value, "unit": "cube-evals/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "configs[2]: synthetic %d-pt shell cloud vs rotated+noised copy (10%% outliers), trimFraction=%.1f, %d^3 DT; "
+                                   "step = 16 rotations x 2 rho-variants x 4680 cubes (octree levels 1-4)" % (nd, TRIM, args.dt),
+                       "points": nd, "dt_size": args.dt, "trimFraction": TRIM, "cube_evals_per_step": evals_per_step, "parallelism": "pairs sharded, 1 rank per GPU"},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": PEAK_HBM_GBPS, "unit": "GB/s", "frac": achieved / PEAK_HBM_GBPS, "traffic": traffic,
+                         "kernel": "k_eval_cubes<1024,5>", "avg_launch_ms": kern_ms, "algorithmic_bytes_per_launch": bytes_per_launch,
+                         "point_lookups_per_sec": value / world * nd},
+            "cpu_baseline": cpu,
+            "registration": reg,
+        }
+        print(json.dumps(line))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def cpu_baseline(g, P, cfg, args, reg):
+    """Times the reference's own InnerBnB (oracle/_ref) on the host cores of this box, replaying the first InnerBnB calls of the
+    GPU registration (same rotations, levels and incumbents => identical searches) until ~cpu_seconds of CPU time are spent."""
+    from oracle import refbind
+    from helpers import rot_cloud
+    jobs = g.job_log() if reg is not None else []
+    if not jobs:
+        return None
+    kind = "reference" if os.path.exists(refbind.REF_SO) else "port"
+    dist_grid, _, _ = g.dt_dump()
+    if kind == "reference":
+        r = refbind.Ref(); r.set_config(cfg); r.set_clouds(P["t"], P["s"]); r.load_dt(g.S, g.geom, dist_grid)
+    else:
+        r = refbind.Oracle(); r.set_config(cfg); r.set_clouds(P["t"], P["s"]); r.load_dt(g.S, g.geom, dist_grid)
+    r.initialize()
+    r.counters(reset=True)
+    spent = 0.0; evals = 0; ncalls = 0; mismatches = 0
+    for j in jobs:
+        r.set_rotated(rot_cloud(j["R"], P["s"]))
+        r.set_opt_error(j["E"])
+        t0 = time.perf_counter()
+        val, _ = r.inner_bnb(j["level"], want_node=False)
+        spent += time.perf_counter() - t0
+        ncalls += 1
+        evals += j["cube_evals"]           # the replayed search is the same search (checked below)
+        if abs(float(val) - float(j["val"])) > 1e-5 * max(1.0, abs(float(val))):
+            mismatches += 1
+        if spent >= args.cpu_seconds:
+            break
+    pops = r.counters(reset=True)[0]
+    if kind == "reference":
+        evals_counted = 8 * (pops - ncalls + r.trans_empty)       # every pop expands 8 cubes except the final threshold break
+    else:
+        evals_counted = evals
+    return {"value": evals_counted / spent, "unit": "cube-evals/s", "cores": 1, "kind": kind,
+            "sample": "first %d InnerBnB calls of this registration replayed by the reference's GoICP::InnerBnB (%d cube-evals, %.1f s, "
+                      "%d result mismatches > 1e-5)" % (ncalls, evals_counted, spent, mismatches),
+            "host_cpus": os.cpu_count()}
+
+
+if __name__ == "__main__":
+    main()

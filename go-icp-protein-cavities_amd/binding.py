@@ -294,6 +294,17 @@ class GoICP:
         e = self.L.goicp_icp(self.h, _ptr(R), _ptr(t), None)
         return np.float32(e), R.reshape(3, 3), t
 
+    def record_jobs(self, on=True):
+        self.L.goicp_record_jobs(self.h, 1 if on else 0)
+
+    def job_log(self):
+        n = self.L.goicp_get_job_log(self.h, None, None, 0)
+        J = (BnbJob * max(n, 1))(); Rr = (BnbResult * max(n, 1))()
+        self.L.goicp_get_job_log(self.h, J, Rr, n)
+        return [dict(R=np.array(list(J[i].R), np.float32).reshape(3, 3), level=int(J[i].rot_level), E=np.float32(J[i].optError_in),
+                     sse=np.float32(J[i].SSEThresh), val=np.float32(Rr[i].optErrorT), cube_evals=int(Rr[i].cube_evals), pops=int(Rr[i].pops))
+                for i in range(n)]
+
     def register(self):
         out = np.zeros(16)
         e = self.L.goicp_register(self.h, _ptr(out))

@@ -63,18 +63,28 @@ __device__ __forceinline__ int cell_of(float v, double mn, double scale) {
     return (int)(((double)v - mn) * scale + 0.5);
 }
 
-// DT3D::Distance (reference jly_3ddt.cpp:1139-1191): one nearest-cell read; out-of-grid extension
-__device__ __forceinline__ float dt_lookup(const DevTables& T, float X, float Y, float Z) {
+// DT3D::Distance (reference jly_3ddt.cpp:1139-1191) split in two so that a lane can put many gathers in flight
+// before it consumes the first one: dt_index() does the (double) cell arithmetic and yields the clamped cell plus
+// the out-of-grid extension length (0 inside the grid); dt_finish() applies the extension to the fetched value.
+__device__ __forceinline__ unsigned dt_index(const DevTables& T, float X, float Y, float Z, float& ext) {
     const int S = T.S;
     int x = cell_of(X, T.xMin, T.scale), y = cell_of(Y, T.yMin, T.scale), z = cell_of(Z, T.zMin, T.scale);
-    if ((unsigned)x < (unsigned)S && (unsigned)y < (unsigned)S && (unsigned)z < (unsigned)S)
-        return T.dist[((size_t)z * S + y) * S + x];
-    float a = 0.f, b = 0.f, c = 0.f;
-    if (x < 0) { a = (float)x; x = 0; } else if (x >= S) { a = (float)(x - S + 1); x = S - 1; }
-    if (y < 0) { b = (float)y; y = 0; } else if (y >= S) { b = (float)(y - S + 1); y = S - 1; }
-    if (z < 0) { c = (float)z; z = 0; } else if (z >= S) { c = (float)(z - S + 1); z = S - 1; }
-    float r = sqrtf(a * a + b * b + c * c);
-    return (float)((double)r / T.scale + (double)T.dist[((size_t)z * S + y) * S + x]);
+    const int ax = x < 0 ? x : (x >= S ? x - S + 1 : 0);
+    const int ay = y < 0 ? y : (y >= S ? y - S + 1 : 0);
+    const int az = z < 0 ? z : (z >= S ? z - S + 1 : 0);
+    x = min(max(x, 0), S - 1); y = min(max(y, 0), S - 1); z = min(max(z, 0), S - 1);
+    ext = 0.f;
+    if ((ax | ay | az) != 0) { const float a = (float)ax, b = (float)ay, c = (float)az; ext = sqrtf(a * a + b * b + c * c); }
+    return (unsigned)((z * S + y) * S + x);
+}
+__device__ __forceinline__ float dt_finish(const DevTables& T, float v, float ext) {
+    if (ext > 0.f) v = (float)((double)ext / T.scale + (double)v);      // float sqrt, double divide and add, rounded to float
+    return v;
+}
+__device__ __forceinline__ float dt_lookup(const DevTables& T, float X, float Y, float Z) {
+    float ext;
+    const unsigned idx = dt_index(T, X, Y, Z, ext);
+    return dt_finish(T, T.dist[idx], ext);
 }
 
 __device__ __forceinline__ size_t clamped_cell(const DevTables& T, float X, float Y, float Z) {
@@ -135,18 +145,20 @@ __device__ __forceinline__ void sweep_tile(const DevTables& T, TileShm<BLOCK>& s
     const int tid = threadIdx.x;
     const int Nd = T.Nd;
     float r[TC][PPT];
+    // gathers: the TC lookups of one point are issued back to back (no consumer in between), so every lane keeps
+    // TC loads in flight; lanes past Nd carry a zero point with zero weight (their residuals are never counted)
 #pragma unroll
     for (int m = 0; m < PPT; m++) {
-        const int i = tid + m * BLOCK;
-        const bool valid = i < Nd;
+        unsigned idx[TC]; float ext[TC], v[TC];
+#pragma unroll
+        for (int j = 0; j < TC; j++) idx[j] = dt_index(T, px[m] + sh.cen[j][0], py[m] + sh.cen[j][1], pz[m] + sh.cen[j][2], ext[j]);
+#pragma unroll
+        for (int j = 0; j < TC; j++) v[j] = T.dist[idx[j]];
 #pragma unroll
         for (int j = 0; j < TC; j++) {
-            float d = 0.f;
-            if (valid) {
-                d = pw[m] * dt_lookup(T, px[m] + sh.cen[j][0], py[m] + sh.cen[j][1], pz[m] + sh.cen[j][2]);
-                if (use_rho) d -= prho[m];
-                if (d < 0.f) d = 0.f;
-            }
+            float d = pw[m] * dt_finish(T, v[j], ext[j]);
+            if (use_rho) d -= prho[m];
+            if (d < 0.f) d = 0.f;
             r[j][m] = d;
         }
     }
@@ -179,6 +191,7 @@ __device__ __forceinline__ void sweep_tile(const DevTables& T, TileShm<BLOCK>& s
     //      (residuals are >= 0, so the bit pattern orders like the value). Replaces intro_select
     //      (reference jly_sorting.hpp:229): the selected multiset is identical, the order is not needed.
     if (T.doTrim) {
+        const int wv = tid >> 6, ln = tid & 63;
         if (tid < TC) { sh.prefix[tid] = 0u; sh.rem[tid] = T.inlierNum - 1; }
         for (int pass = 3; pass >= 0; pass--) {
             for (int k = tid; k < TC * 256; k += BLOCK) (&sh.hist[0][0])[k] = 0u;
@@ -186,21 +199,46 @@ __device__ __forceinline__ void sweep_tile(const DevTables& T, TileShm<BLOCK>& s
             const unsigned himask = pass == 3 ? 0u : (0xFFFFFFFFu << (8 * (pass + 1)));
 #pragma unroll
             for (int m = 0; m < PPT; m++) {
-                if (tid + m * BLOCK < Nd) {
+                const bool valid = tid + m * BLOCK < Nd;
 #pragma unroll
-                    for (int j = 0; j < TC; j++) {
-                        unsigned bits = __float_as_uint(r[j][m]);
-                        if (((bits ^ sh.prefix[j]) & himask) == 0u) atomicAdd(&sh.hist[j][(bits >> (8 * pass)) & 255u], 1u);
+                for (int j = 0; j < TC; j++) {
+                    const unsigned bits = __float_as_uint(r[j][m]);
+                    const bool take = valid && ((bits ^ sh.prefix[j]) & himask) == 0u;
+                    const unsigned dgt = (bits >> (8 * pass)) & 255u;
+                    if (pass == 3) {
+                        // the top byte (sign + 7 exponent bits) takes a handful of values per wave: count each distinct
+                        // value once per wave instead of letting 64 lanes serialise on one LDS word
+                        unsigned long long todo = __ballot(take);
+                        while (todo) {
+                            const int leader = __ffsll((long long)todo) - 1;
+                            const unsigned d0 = __shfl(dgt, leader, 64);
+                            const unsigned long long same = __ballot(take && dgt == d0) & todo;
+                            if (ln == leader) atomicAdd(&sh.hist[j][d0], (unsigned)__popcll(same));
+                            todo &= ~same;
+                        }
+                    } else if (take) {
+                        atomicAdd(&sh.hist[j][dgt], 1u);
                     }
                 }
             }
             __syncthreads();
-            if (tid < TC) {
-                int rem = sh.rem[tid];
-                unsigned dgt = 0;
-                for (; dgt < 255u; dgt++) { int h = (int)sh.hist[tid][dgt]; if (rem < h) break; rem -= h; }
-                sh.prefix[tid] |= dgt << (8 * pass);
-                sh.rem[tid] = rem;
+            // one wave per cube scans its 256 bins: 4 bins per lane + wave prefix sum
+            for (int j = wv; j < TC; j += BLOCK / 64) {
+                const unsigned c0 = sh.hist[j][4 * ln], c1 = sh.hist[j][4 * ln + 1], c2 = sh.hist[j][4 * ln + 2], c3 = sh.hist[j][4 * ln + 3];
+                const int mine = (int)(c0 + c1 + c2 + c3);
+                int incl = mine;
+#pragma unroll
+                for (int off = 1; off < 64; off <<= 1) { const int t = __shfl_up(incl, off, 64); if (ln >= off) incl += t; }
+                const int rem = sh.rem[j];
+                const unsigned long long over = __ballot(incl > rem);
+                const int owner = over ? __ffsll((long long)over) - 1 : 63;
+                if (ln == owner) {
+                    int rr = rem - (incl - mine);
+                    unsigned dgt = 4u * ln;
+                    if (rr >= (int)c0) { rr -= (int)c0; dgt++; if (rr >= (int)c1) { rr -= (int)c1; dgt++; if (rr >= (int)c2) { rr -= (int)c2; dgt++; } } }
+                    sh.prefix[j] |= dgt << (8 * pass);
+                    sh.rem[j] = rr;
+                }
             }
             __syncthreads();
         }
@@ -546,32 +584,30 @@ __global__ void k_point_eval(DevTables T, const double* __restrict__ Rt /*R[9], 
 }
 
 // exhaustive 1-NN in float with the distance expression of the reference's kd-tree metric
-// (jly_icp3d.hpp:54-60); strict '<' keeps the lowest model index among exact ties.
-#define NN_TILE 1024
+// (jly_icp3d.hpp:54-60). One wave per query point: lane l scans model points l, l+64, ... (strict '<' keeps the
+// first, i.e. lowest, index of its stride), then the wave reduces on (distance, index) so that the lowest model
+// index wins among exact ties.
 __global__ __launch_bounds__(256) void k_icp_nn(DevTables T, const float* __restrict__ mxyz, const float* __restrict__ Rt /*float R[9], t[3]*/,
                                                  int* __restrict__ id_out, float* __restrict__ d_out) {
-    __shared__ float sm[NN_TILE * 3];
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    float q0 = 0.f, q1 = 0.f, q2 = 0.f;
-    if (i < T.Nd) {
-        const float d0 = T.dxyz[3 * i], d1 = T.dxyz[3 * i + 1], d2 = T.dxyz[3 * i + 2];
-        q0 = Rt[0] * d0 + Rt[1] * d1 + Rt[2] * d2 + Rt[9];
-        q1 = Rt[3] * d0 + Rt[4] * d1 + Rt[5] * d2 + Rt[10];
-        q2 = Rt[6] * d0 + Rt[7] * d1 + Rt[8] * d2 + Rt[11];
+    const int lane = threadIdx.x & 63;
+    const int i = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (i >= T.Nd) return;                         // whole waves leave together
+    const float d0 = T.dxyz[3 * i], d1 = T.dxyz[3 * i + 1], d2 = T.dxyz[3 * i + 2];
+    const float q0 = Rt[0] * d0 + Rt[1] * d1 + Rt[2] * d2 + Rt[9];
+    const float q1 = Rt[3] * d0 + Rt[4] * d1 + Rt[5] * d2 + Rt[10];
+    const float q2 = Rt[6] * d0 + Rt[7] * d1 + Rt[8] * d2 + Rt[11];
+    float best = INFINITY; int bi = 0x7fffffff;
+    for (int m = lane; m < T.Nm; m += 64) {
+        const float e0 = q0 - mxyz[3 * m], e1 = q1 - mxyz[3 * m + 1], e2 = q2 - mxyz[3 * m + 2];
+        const float d = e0 * e0 + e1 * e1 + e2 * e2;
+        if (d < best) { best = d; bi = m; }
     }
-    float best = INFINITY; int bi = 0;
-    for (int base = 0; base < T.Nm; base += NN_TILE) {
-        const int cnt = min(NN_TILE, T.Nm - base);
-        __syncthreads();
-        for (int k = threadIdx.x; k < cnt * 3; k += blockDim.x) sm[k] = mxyz[(size_t)base * 3 + k];
-        __syncthreads();
-        for (int m = 0; m < cnt; m++) {
-            const float e0 = q0 - sm[3 * m], e1 = q1 - sm[3 * m + 1], e2 = q2 - sm[3 * m + 2];
-            const float d = e0 * e0 + e1 * e1 + e2 * e2;
-            if (d < best) { best = d; bi = base + m; }
-        }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        const float ob = __shfl_down(best, off, 64); const int oi = __shfl_down(bi, off, 64);
+        if (ob < best || (ob == best && oi < bi)) { best = ob; bi = oi; }
     }
-    if (i < T.Nd) { id_out[i] = bi; d_out[i] = best; }
+    if (lane == 0) { id_out[i] = bi; d_out[i] = best; }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -628,13 +664,16 @@ extern "C" void goicp_engine_destroy(goicp_engine* h) {
 }
 
 static void pick_geometry(goicp_engine* h) {
+    // lanes x points-per-lane; the residuals of a tile (TC x PPT floats per lane) stay in registers across the
+    // selection passes, so large clouds use 512-lane workgroups (256 VGPRs per lane) instead of 1024 (128 VGPRs)
     const int Nd = h->T.Nd;
     if (Nd <= 256) { h->block = 256; h->ppt = 1; }
     else if (Nd <= 512) { h->block = 256; h->ppt = 2; }
     else if (Nd <= 1024) { h->block = 1024; h->ppt = 1; }
     else if (Nd <= 2048) { h->block = 1024; h->ppt = 2; }
     else if (Nd <= 4096) { h->block = 1024; h->ppt = 4; }
-    else { h->block = 1024; h->ppt = 8; }
+    else if (Nd <= 5120) { h->block = 1024; h->ppt = 5; }
+    else { h->block = 512; h->ppt = 16; }
     h->dyn_lds = (h->T.exact && !h->T.doTrim) ? (size_t)TC * Nd * sizeof(float) : 0;
 }
 
@@ -792,7 +831,8 @@ static int ensure_fpscratch(goicp_engine* h, size_t blocks) {
         else if (h->block == 1024 && h->ppt == 1) { CALL(1024, 1); }         \
         else if (h->block == 1024 && h->ppt == 2) { CALL(1024, 2); }         \
         else if (h->block == 1024 && h->ppt == 4) { CALL(1024, 4); }         \
-        else { CALL(1024, 8); }                                              \
+        else if (h->block == 1024 && h->ppt == 5) { CALL(1024, 5); }         \
+        else { CALL(512, 16); }                                              \
     } while (0)
 
 extern "C" int goicp_engine_eval_cubes_dev(goicp_engine* h, int slot, int rot_level, const void* cubes_dev, int n, void* ub_dev, void* lb_dev) {
@@ -927,7 +967,7 @@ extern "C" int goicp_engine_icp_nn(goicp_engine* h, const double* R9, const doub
     for (int k = 0; k < 9; k++) Rt[k] = (float)R9[k];
     for (int k = 0; k < 3; k++) Rt[9 + k] = (float)t3[k];
     HIPCHK(h, hipMemcpyAsync(h->d_Rtf, Rt, sizeof Rt, hipMemcpyHostToDevice, h->stream));
-    hipLaunchKernelGGL(k_icp_nn, dim3((h->T.Nd + 255) / 256), dim3(256), 0, h->stream, h->T, h->d_mxyz, h->d_Rtf, h->d_int, h->d_dist);
+    hipLaunchKernelGGL(k_icp_nn, dim3((h->T.Nd + 3) / 4), dim3(256), 0, h->stream, h->T, h->d_mxyz, h->d_Rtf, h->d_int, h->d_dist);
     HIPCHK(h, hipGetLastError());
     HIPCHK(h, hipMemcpyAsync(id_model, h->d_int, (size_t)h->T.Nd * sizeof(int), hipMemcpyDeviceToHost, h->stream));
     HIPCHK(h, hipMemcpyAsync(dist_sq, h->d_dist, (size_t)h->T.Nd * sizeof(float), hipMemcpyDeviceToHost, h->stream));

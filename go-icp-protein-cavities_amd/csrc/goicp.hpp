@@ -112,6 +112,9 @@ public:
     std::string error_message;
     RegisterStats stats;
     std::vector<std::pair<std::string, float>> trace;   // ("Init"|"ICP"|"BNB", Error*) in order
+    int record_jobs = 0;          // keep the consumed InnerBnB jobs (for CPU-baseline replays)
+    std::vector<goicp_bnb_job> job_log;
+    std::vector<goicp_bnb_result> result_log;
 
     // state shared with tests through the C API
     std::vector<float> weights;            // [Nd]

@@ -158,6 +158,14 @@ int goicp_get_stats(goicp_handle* h, uint64_t* s, double* ms) {
     return GOICP_OK;
 }
 
+void goicp_record_jobs(goicp_handle* h, int on) { if (h) h->g.record_jobs = on; }
+int goicp_get_job_log(goicp_handle* h, goicp_bnb_job* jobs, goicp_bnb_result* results, int cap) {
+    if (!h) return 0;
+    const int n = (int)h->g.job_log.size();
+    for (int i = 0; i < n && i < cap; i++) { if (jobs) jobs[i] = h->g.job_log[i]; if (results) results[i] = h->g.result_log[i]; }
+    return n;
+}
+
 // ---- file pipeline (reference jly_main.cpp:54-179) -------------------------------------------------------
 static std::string stem_between(const std::string& s) {   // substr(find("/")+1, find(".")-find("/")-1), jly_main.cpp:65-66
     const size_t a = s.find("/"), b = s.find(".");

@@ -496,7 +496,7 @@ float GoICP::OuterBnB() {
         // Speculative batch: the (<=16) InnerBnB calls of this pop are independent searches as long as the incumbent
         // optError does not change in between, so they are launched together; a result is consumed only if the incumbent
         // it was computed with is still current, otherwise the rest of the pop is re-launched with the new incumbent.
-        goicp_bnb_result res[16]; float res_E[16]; bool have[16];
+        goicp_bnb_result res[16]; goicp_bnb_job res_job[16]; float res_E[16]; bool have[16];
         for (int k = 0; k < 16; k++) have[k] = false;
         auto launch_from = [&](int first) -> bool {
             goicp_bnb_job jobs[16]; int slot[16]; int n = 0;
@@ -512,7 +512,7 @@ float GoICP::OuterBnB() {
             status = goicp_engine_inner_bnb_batch(eng_, jobs, n, out);
             stats.inner_launches++; stats.inner_jobs_launched += n;
             if (status != GOICP_OK) return false;
-            for (int q = 0; q < n; q++) { res[slot[q]] = out[q]; res_E[slot[q]] = optError; have[slot[q]] = true; }
+            for (int q = 0; q < n; q++) { res[slot[q]] = out[q]; res_job[slot[q]] = jobs[q]; res_E[slot[q]] = optError; have[slot[q]] = true; }
             return true;
         };
         auto get = [&](int k) -> const goicp_bnb_result* {
@@ -521,6 +521,7 @@ float GoICP::OuterBnB() {
                 if (!launch_from(k)) return nullptr;
             }
             stats.inner_calls++; stats.cube_evals += res[k].cube_evals; stats.trans_pops += res[k].pops;
+            if (record_jobs) { job_log.push_back(res_job[k]); result_log.push_back(res[k]); }
             return &res[k];
         };
         for (int j = 0; j < 8; j++) {
@@ -566,7 +567,7 @@ float GoICP::OuterBnB() {
 }
 
 float GoICP::Register() {
-    trace.clear(); stats = RegisterStats();
+    trace.clear(); stats = RegisterStats(); job_log.clear(); result_log.clear();
     Initialize();
     if (!eng_) return std::numeric_limits<float>::quiet_NaN();
     OuterBnB();

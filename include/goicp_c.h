@@ -55,6 +55,10 @@ int goicp_get_trace(goicp_handle*, int32_t* tags, float* values, int cap);
 /* stats8: rot_pops, inner_calls, inner_launches, inner_jobs_launched, cube_evals, trans_pops, icp_calls, icp_iters */
 int goicp_get_stats(goicp_handle*, uint64_t* stats8, double* engine_kernel_ms);
 
+/* consumed InnerBnB jobs of the last goicp_register (enable with goicp_record_jobs(h,1) before it); returns count */
+void goicp_record_jobs(goicp_handle*, int on);
+int goicp_get_job_log(goicp_handle*, goicp_bnb_job* jobs, goicp_bnb_result* results, int cap);
+
 /* ---- file pipeline of the reference's main() (jly_main.cpp:54-179) ------------------------------------
  * argv semantics: <TARGET mol2> <SOURCE mol2> <Nd downsample> <CONFIG> <OUTPUT> <PAIR#>; reads cfpfh/<name>.cfpfh next to
  * `base_dir` (the directory that holds cavities/ cfpfh/ cavitiesN/), writes cavitiesN/<name>_sim<k>N.xyz, <OUTPUT>

@@ -29,6 +29,7 @@ static bool g_trace_on = false;
 static size_t g_trace_cap = 0;
 static long long g_trans_pops = 0;
 static long long g_rot_pops = 0;
+static long long g_trans_empty = 0;   // InnerBnB loops that ended on an empty queue
 
 #include <algorithm>
 #include <stdexcept>
@@ -52,17 +53,19 @@ template <> struct trace_log<TRANSNODE> {
         }
     }
     static void pop() { g_trans_pops++; }
+    static void empty_hit() { g_trans_empty++; }
 };
 template <> struct trace_log<ROTNODE> {
     static void push(const ROTNODE&) {}
     static void pop() { g_rot_pops++; }
+    static void empty_hit() {}
 };
 
 template <class T>
 class traced_priority_queue {
     std::priority_queue<T> q_;
 public:
-    bool empty() const { return q_.empty(); }
+    bool empty() const { bool e = q_.empty(); if (e) trace_log<T>::empty_hit(); return e; }
     size_t size() const { return q_.size(); }
     const T& top() const { return q_.top(); }
     void pop() { trace_log<T>::pop(); q_.pop(); }
@@ -177,6 +180,19 @@ void ref_dt_dump(void* hv, float* dist, short* vhd, int* nearest, int* cellc) {
     }
 }
 
+// Adopt a distance grid built elsewhere (geometric path only: the cell tables stay unbuilt, so the handle must
+// run with regularization == regularizationFPFH == 0 and only through ref_inner_bnb / ref_distance).
+void ref_load_dt(void* hv, int S, const double* geom4, const float* dist) {
+    DT3D& d = ((RefHandle*)hv)->g.dt;
+    d.SIZE = S; d.xMin = geom4[0]; d.yMin = geom4[1]; d.zMin = geom4[2]; d.scale = geom4[3];
+    d.xMax = d.xMin + S / d.scale; d.yMax = d.yMin + S / d.scale; d.zMax = d.zMin + S / d.scale;
+    if (d.A.data == NULL) d.A.Init(S, S, S);
+    size_t k = 0;
+    for (int z = 0; z < S; z++) for (int y = 0; y < S; y++) for (int x = 0; x < S; x++, k++) {
+        d.A.data[z][y][x].distance = dist[k]; d.A.data[z][y][x].v = d.A.data[z][y][x].h = d.A.data[z][y][x].d = 0;
+    }
+}
+
 int ref_cell_points(void* hv, int x, int y, int z, int* out, int cap) {
     DT3D& d = ((RefHandle*)hv)->g.dt;
     const std::vector<int>& v = d.cellPoints[z][y][x].points;
@@ -278,8 +294,8 @@ long long ref_trace_end(float* out /*[n*6]*/, long long cap) {
     return n;
 }
 void ref_counters(long long* out, int reset) {
-    out[0] = g_trans_pops; out[1] = g_rot_pops;
-    if (reset) { g_trans_pops = 0; g_rot_pops = 0; }
+    out[0] = g_trans_pops; out[1] = g_rot_pops; out[2] = g_trans_empty;
+    if (reset) { g_trans_pops = 0; g_rot_pops = 0; g_trans_empty = 0; }
 }
 
 // jly_sorting.hpp:229 on a caller-owned array

@@ -268,9 +268,17 @@ class Ref:
         return buf.reshape(-1, 6)[:min(n, self._cap)].copy()
 
     def counters(self, reset=True):
-        out = np.zeros(2, np.int64)
+        out = np.zeros(3, np.int64)
         self.lib.ref_counters(_p(out, C.c_longlong), 1 if reset else 0)
+        self.trans_empty = int(out[2])
         return int(out[0]), int(out[1])
+
+    def load_dt(self, S, geom8, dist):
+        """geometric path only (no cell tables): adopt a distance grid built by another builder."""
+        g4 = np.array([geom8[0], geom8[2], geom8[4], geom8[6]], np.float64)
+        dist = np.ascontiguousarray(dist, dtype=np.float32)
+        self.lib.ref_load_dt(self.h, int(S), _p(g4, C.c_double), _p(dist, C.c_float))
+        self.geom = np.asarray(geom8, np.float64); self.S = int(S)
 
     def intro_select(self, data, k):
         d = np.ascontiguousarray(data, dtype=np.float32).copy()

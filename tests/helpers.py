@@ -42,7 +42,7 @@ def oracle_for(P, cfgvec, H=None, nd=None):
     return o
 
 
-def synth_pair(n, seed=20260101, noise=0.01, outlier_frac=0.10, tmax=0.2):
+def synth_pair(n, seed=20260101, noise=0.01, outlier_frac=0.10, tmax=0.2, theta_range=(0.3, np.pi)):
     """SURVEY.md 8(d) synthetic generator: shell cloud on 6 overlapping spheres, centred, max-norm 1,
     6 significant digits; data = permuted, rotated, translated, noised copy with outliers."""
     rng = np.random.default_rng(seed)
@@ -53,7 +53,7 @@ def synth_pair(n, seed=20260101, noise=0.01, outlier_frac=0.10, tmax=0.2):
     m -= m.mean(0); m /= np.linalg.norm(m, axis=1).max()
     m = np.array([[float("%g" % x) for x in row] for row in m])
     rng2 = np.random.default_rng(seed + 1)
-    aa = rng2.normal(size=3); aa = aa / np.linalg.norm(aa) * rng2.uniform(0.3, np.pi)
+    aa = rng2.normal(size=3); aa = aa / np.linalg.norm(aa) * rng2.uniform(*theta_range)
     th = np.linalg.norm(aa); k = aa / th
     K = np.array([[0, -k[2], k[1]], [k[2], 0, -k[0]], [-k[1], k[0], 0]])
     Rt = np.eye(3) + np.sin(th) * K + (1 - np.cos(th)) * K @ K
