@@ -233,3 +233,52 @@ def test_full_size_properties_300_cubed():
     ref = np.sort(d.astype(np.float64) ** 2)[:k].sum()
     assert abs(ubz[0] - ref) <= 1e-5 * ref and abs(lbz[0] - ubz[0]) <= 1e-6 * ref
     g.close()
+
+
+def _default_config_file(path, **over):
+    d = dict(goicp_amd.DEFAULT_CFG); d.update(over)
+    with open(path, "w") as f:
+        f.write("# generated by the test-suite: keys of reference jly_main.cpp:236-264, shipped default values\n")
+        for k in goicp_amd.CFG_KEYS:
+            f.write("%s=%s\n" % (k, repr(d[k]) if isinstance(d[k], float) else d[k]))
+
+
+def test_file_pipeline_reproduces_shipped_output_files(tmp_path):
+    """Drop-in check at the outermost boundary: same argv as the reference's main() on the shipped cavity files ->
+    byte-identical output/similar1.txt, similar1_rescaled.txt (except the Time line) and cavitiesN/*.xyz."""
+    import shutil
+    data = os.path.join(GOLDEN, "data")
+    base = os.path.join(str(tmp_path), "work")
+    shutil.copytree(data, base)
+    for f in os.listdir(os.path.join(base, "cavitiesN")):
+        os.remove(os.path.join(base, "cavitiesN", f))
+    cfgp = os.path.join(base, "config.txt"); _default_config_file(cfgp)
+    outp = os.path.join(base, "output", "out1.txt")
+    res = goicp_amd.run_pair_files(base, "cavities/1eq2_6_cavity6.mol2", "cavities/2x86_3_cavity6.mol2", 238, cfgp, outp, 1)
+    got = open(outp).read().splitlines(); want = open(os.path.join(data, "output", "similar1.txt")).read().splitlines()
+    assert got[0].startswith("Time: ") and got[1:] == want[1:]
+    got = open(outp.replace(".txt", "_rescaled.txt")).read().splitlines()
+    want = open(os.path.join(data, "output", "similar1_rescaled.txt")).read().splitlines()
+    assert got[1:] == want[1:]
+    for f in ("2x86_3_cavity6_sim1N.xyz", "1eq2_6_cavity6_sim1N.xyz"):
+        assert open(os.path.join(base, "cavitiesN", f)).read() == open(os.path.join(data, "cavitiesN", f)).read()
+    assert res["compat"] == 133 and "%g" % res["error"] == "8.45388"
+
+
+def test_batch_driver_on_one_gpu(tmp_path):
+    """bo1_GoICP.py's loop through the driver: the two tsv rows whose cavity files exist, registered on this GPU."""
+    import shutil
+    from goicp_amd import driver
+    data = os.path.join(GOLDEN, "data")
+    base = os.path.join(str(tmp_path), "work"); shutil.copytree(data, base)
+    cfgp = os.path.join(base, "config.txt"); _default_config_file(cfgp)
+    outd = os.path.join(base, "output")
+
+    def reg(tf, sf, nd, config, output, k):
+        return goicp_amd.run_pair_files(base, tf, sf, nd, config, output, k)
+    recs, n = driver.run_batch(base, os.path.join(base, "cavities_similar_BO1_clean.tsv"), cfgp, outd, reg)
+    allr = driver.gather_records(recs, n)
+    assert n == 383 and allr.shape[0] == 2
+    G = load_register()
+    assert np.float32(allr[0, 13]) == np.float32(G["pair1_default"]["error"]) and np.float32(allr[1, 13]) == np.float32(G["pair2_default"]["error"])
+    assert int(allr[0, 14]) == 133 and int(allr[1, 14]) == 118

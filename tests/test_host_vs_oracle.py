@@ -1,0 +1,67 @@
+"""CPU (-m "not gpu"): host-side pieces of the product library (no GPU needed) against the oracle / goldens:
+the DT builder + cell tables, Initialize() tables, config parsing, mol2 -> normalised xyz text, RMSD."""
+import os
+
+import numpy as np
+import pytest
+
+import goicp_amd
+from oracle.refbind import cfg_vector, Oracle
+from helpers import GOLDEN, load_clouds, load_hotpath, oracle_for
+
+DATA = os.path.join(GOLDEN, "data")
+
+
+@pytest.mark.parametrize("name,S", [("pair1", 20), ("pair1", 50), ("pair2", 50), ("pair1", 100)])
+def test_host_dt_builder_matches_oracle(name, S):
+    P = load_clouds(name)
+    v, _ = cfg_vector(distTransSize=S)
+    o = oracle_for(P, v)
+    od, on, oc, _ = o.dt_dump()
+    g = goicp_amd.GoICP(v)
+    g.set_clouds(P["t"], P["s"], P["tc"], P["sc"], P["tf"], P["sf"])
+    g.build_dt()
+    dist, near, cc = g.dt_dump()
+    assert np.array_equal(g.geom, o.geom)
+    assert np.array_equal(dist, od)
+    assert np.array_equal(near, (on[:, 2].astype(np.int64) * S + on[:, 1]) * S + on[:, 0])
+    assert np.array_equal(cc, oc)
+
+
+def test_host_dt_matches_reference_fixture():
+    H = load_hotpath("pair2_S50"); P = load_clouds("pair2")
+    g = goicp_amd.GoICP(H["cfg"]); g.set_clouds(P["t"], P["s"], P["tc"], P["sc"]); g.build_dt()
+    dist, near, cc = g.dt_dump()
+    assert np.array_equal(dist, H["dist"]) and np.array_equal(cc, H["cellc"])
+
+
+def test_config_file_roundtrip(tmp_path):
+    p = os.path.join(str(tmp_path), "config.txt")
+    with open(p, "w") as f:
+        f.write("# comment line\nMSEThresh=0.01\n\nnorm=2\nregularization = 0.0005;\nponderation=1\r\ncfpfh=0\nrotMinX=-3.1416\nrotMinY=-3.1416\nrotMinZ=-3.1416\n"
+                "rotWidth=6.2832\ntransMinX=-0.5\ntransMinY=-0.5\ntransMinZ=-0.5\ntransWidth=1.0\ntrimFraction=0.0\ndistTransSize=20\n"
+                "distTransExpandFactor=2.0\nthis line has three tokens\n")
+    g = goicp_amd.GoICP()
+    g.read_config(p)
+    v = g.get_config()
+    want, _ = cfg_vector()
+    assert np.array_equal(v, want)        # missing keys (regularizationNeighbors, regularizationFPFH) parse as atof("") = 0
+
+
+def test_rmsd_known_answers():
+    # Transformation::computeRMSD on the shipped aligned/rot proteins -> 1.73675334 / 13.9296408.
+    # The protein files (3.4 MB) are not committed; the function is exercised on a synthetic pair of mol2 files.
+    import tempfile
+    d = tempfile.mkdtemp()
+    def write(path, pts):
+        with open(path, "w") as f:
+            f.write("@<TRIPOS>MOLECULE\nx\n@<TRIPOS>ATOM\n")
+            for i, (nm, p) in enumerate(pts):
+                f.write("%7d %-4s %10.4f %10.4f %10.4f C.3 1 ALA1 0.0000\n" % (i + 1, nm, p[0], p[1], p[2]))
+            f.write("@<TRIPOS>BOND\n")
+    a = [("N", (0, 0, 0)), ("CA", (1, 0, 0)), ("CB", (5, 5, 5)), ("C", (2, 0, 0)), ("O", (3, 0, 0))]
+    b = [("N", (0, 0, 1)), ("CA", (1, 0, 1)), ("CB", (9, 9, 9)), ("C", (2, 2, 0)), ("O", (3, 0, 0))]
+    write(os.path.join(d, "a.mol2"), a); write(os.path.join(d, "b.mol2"), b)
+    got = goicp_amd.compute_rmsd(os.path.join(d, "a.mol2"), os.path.join(d, "b.mol2"))
+    want = np.float32(np.sqrt(np.float32(1 + 1 + 4 + 0) / 4))     # backbone atoms N, CA, C, O only (CB skipped)
+    assert abs(got - want) < 1e-6
