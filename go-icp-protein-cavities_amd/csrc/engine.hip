@@ -21,6 +21,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 #include <math.h>
 #include <string>
@@ -51,6 +52,7 @@ struct DevTables {
     int Nd, Nm, inlierNum, doTrim, norm, b0, b1;
     float reg, regFPFH;
     int use_compat, use_fpfh, exact;
+    int dbg;                 // GOICP_DBG ablation bits (diagnosis only; results are wrong when set)
 };
 
 struct HeapNode { float x, y, z, w, ub, lb; };
@@ -119,14 +121,29 @@ __device__ __forceinline__ double wave_sum(double v) {
     return v;
 }
 
+// Histogram increment for a whole wave. Residual sets are often dominated by one value (every residual that the
+// rotation-uncertainty radius clamps to 0 is bit-identical), and 64 lanes adding to one LDS word serialise; so the
+// lanes that share the first taker's key are counted with one ballot and added once, the others add individually.
+__device__ __forceinline__ void hist_add(unsigned* row, unsigned key, bool take, int ln) {
+    const unsigned long long tk = __ballot(take);
+    if (!tk) return;
+    const int leader = __ffsll((long long)tk) - 1;
+    const unsigned k0 = (unsigned)__shfl((int)key, leader, 64);
+    const unsigned long long same = __ballot(take && key == k0);
+    if (ln == leader) atomicAdd(&row[k0], (unsigned)__popcll(same));
+    if (take && key != k0) atomicAdd(&row[key], 1u);
+}
+
 template <int BLOCK>
 struct TileShm {
     float cube[TC][4];        // x, y, z, w
     float cen[TC][3];         // centre translation
     float mtd[TC];            // maxTransDis
-    unsigned hist[TC][256];
+    unsigned hist[TC][1024];  // radix-select histograms (first pass 1024 bins, later passes 256)
     unsigned prefix[TC];
     int rem[TC];
+    unsigned maxb[TC];        // bit pattern of the largest residual per cube
+    int fallback;
     double red[BLOCK / 64][2 * TC];
     float ub[TC], lb[TC];
     float lat[NLMAX][3];
@@ -153,7 +170,7 @@ __device__ __forceinline__ void sweep_tile(const DevTables& T, TileShm<BLOCK>& s
 #pragma unroll
         for (int j = 0; j < TC; j++) idx[j] = dt_index(T, px[m] + sh.cen[j][0], py[m] + sh.cen[j][1], pz[m] + sh.cen[j][2], ext[j]);
 #pragma unroll
-        for (int j = 0; j < TC; j++) v[j] = T.dist[idx[j]];
+        for (int j = 0; j < TC; j++) v[j] = T.dist[(T.dbg & 2) ? (idx[j] & 1023u) : idx[j]];
 #pragma unroll
         for (int j = 0; j < TC; j++) {
             float d = pw[m] * dt_finish(T, v[j], ext[j]);
@@ -190,11 +207,72 @@ __device__ __forceinline__ void sweep_tile(const DevTables& T, TileShm<BLOCK>& s
     // ---- inlier threshold per cube: k-th smallest residual by 4x8-bit radix select on the float bits
     //      (residuals are >= 0, so the bit pattern orders like the value). Replaces intro_select
     //      (reference jly_sorting.hpp:229): the selected multiset is identical, the order is not needed.
-    if (T.doTrim) {
+    // ---- inlier threshold per cube = the inlierNum-th smallest residual, by MSB-first radix select on the float bit
+    //      pattern (residuals are >= 0, so the pattern orders like the value) with LDS histograms. Replaces intro_select
+    //      (reference jly_sorting.hpp:229): the selected multiset is the same, the order is not needed (order-free sums).
+    unsigned thr[TC]; int below[TC];
+#pragma unroll
+    for (int j = 0; j < TC; j++) { thr[j] = 0u; below[j] = 0; }
+    if (T.doTrim && !(T.dbg & 1)) {
         const int wv = tid >> 6, ln = tid & 63;
-        if (tid < TC) { sh.prefix[tid] = 0u; sh.rem[tid] = T.inlierNum - 1; }
-        for (int pass = 3; pass >= 0; pass--) {
-            for (int k = tid; k < TC * 256; k += BLOCK) (&sh.hist[0][0])[k] = 0u;
+        for (int k = tid; k < TC * 1024; k += BLOCK) (&sh.hist[0][0])[k] = 0u;
+        if (tid < TC) { sh.prefix[tid] = 0u; sh.rem[tid] = T.inlierNum - 1; sh.maxb[tid] = 0u; }
+        if (tid == 0) sh.fallback = 0;
+        __syncthreads();
+        // (1) largest residual per cube: fixes the 8-octave window of the first pass
+#pragma unroll
+        for (int j = 0; j < TC; j++) {
+            unsigned mx = 0u;
+#pragma unroll
+            for (int m = 0; m < PPT; m++) if (tid + m * BLOCK < Nd) mx = max(mx, __float_as_uint(r[j][m]));
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) mx = max(mx, (unsigned)__shfl_down((int)mx, off, 64));
+            if (ln == 0) atomicMax(&sh.maxb[j], mx);
+        }
+        __syncthreads();
+        // (2) first pass: 10-bit digit = top 16 bits (sign, exponent, 7 mantissa bits) relative to the cube's maximum:
+        //     1024 monotone bins over the 8 octaves below the maximum, so the values spread over hundreds of LDS words
+        //     instead of piling onto the 2-3 exponent bytes a plain byte pass would see
+#pragma unroll
+        for (int m = 0; m < PPT; m++) {
+            const bool valid = tid + m * BLOCK < Nd;
+#pragma unroll
+            for (int j = 0; j < TC; j++) {
+                const int base16 = max(0, (int)(sh.maxb[j] >> 16) - 1023);
+                const int key = max(0, (int)(__float_as_uint(r[j][m]) >> 16) - base16);
+                hist_add(sh.hist[j], (unsigned)key, valid, ln);
+            }
+        }
+        __syncthreads();
+        for (int j = wv; j < TC; j += BLOCK / 64) {     // one wave scans the 1024 bins of a cube: 16 per lane
+            unsigned c[16]; int mine = 0;
+#pragma unroll
+            for (int q = 0; q < 16; q++) { c[q] = sh.hist[j][16 * ln + q]; mine += (int)c[q]; }
+            int incl = mine;
+#pragma unroll
+            for (int off = 1; off < 64; off <<= 1) { const int t = __shfl_up(incl, off, 64); if (ln >= off) incl += t; }
+            const int rem = sh.rem[j];
+            const unsigned long long over = __ballot(incl > rem);
+            const int owner = over ? __ffsll((long long)over) - 1 : 63;
+            if (ln == owner) {
+                int rr = rem - (incl - mine);
+                int b = 0;
+#pragma unroll
+                for (int q = 0; q < 15; q++) { if (b == q && rr >= (int)c[q]) { rr -= (int)c[q]; b = q + 1; } }
+                const int bin = 16 * ln + b;
+                const int base16 = max(0, (int)(sh.maxb[j] >> 16) - 1023);
+                if (bin == 0 && base16 > 0) sh.fallback = 1;      // threshold below the window: generic passes decide
+                sh.prefix[j] = (unsigned)(base16 + bin) << 16;
+                sh.rem[j] = rr;
+            }
+        }
+        __syncthreads();
+        const bool generic = sh.fallback != 0;
+        if (generic) { if (tid < TC) { sh.prefix[tid] = 0u; sh.rem[tid] = T.inlierNum - 1; } }
+        // (3) remaining bytes, MSB first (all four when the window missed)
+        for (int pass = generic ? 3 : 1; pass >= 0; pass--) {
+            __syncthreads();
+            for (int k = tid; k < TC * 256; k += BLOCK) sh.hist[k >> 8][k & 255] = 0u;
             __syncthreads();
             const unsigned himask = pass == 3 ? 0u : (0xFFFFFFFFu << (8 * (pass + 1)));
 #pragma unroll
@@ -204,25 +282,10 @@ __device__ __forceinline__ void sweep_tile(const DevTables& T, TileShm<BLOCK>& s
                 for (int j = 0; j < TC; j++) {
                     const unsigned bits = __float_as_uint(r[j][m]);
                     const bool take = valid && ((bits ^ sh.prefix[j]) & himask) == 0u;
-                    const unsigned dgt = (bits >> (8 * pass)) & 255u;
-                    if (pass == 3) {
-                        // the top byte (sign + 7 exponent bits) takes a handful of values per wave: count each distinct
-                        // value once per wave instead of letting 64 lanes serialise on one LDS word
-                        unsigned long long todo = __ballot(take);
-                        while (todo) {
-                            const int leader = __ffsll((long long)todo) - 1;
-                            const unsigned d0 = __shfl(dgt, leader, 64);
-                            const unsigned long long same = __ballot(take && dgt == d0) & todo;
-                            if (ln == leader) atomicAdd(&sh.hist[j][d0], (unsigned)__popcll(same));
-                            todo &= ~same;
-                        }
-                    } else if (take) {
-                        atomicAdd(&sh.hist[j][dgt], 1u);
-                    }
+                    hist_add(sh.hist[j], (bits >> (8 * pass)) & 255u, take, ln);
                 }
             }
             __syncthreads();
-            // one wave per cube scans its 256 bins: 4 bins per lane + wave prefix sum
             for (int j = wv; j < TC; j += BLOCK / 64) {
                 const unsigned c0 = sh.hist[j][4 * ln], c1 = sh.hist[j][4 * ln + 1], c2 = sh.hist[j][4 * ln + 2], c3 = sh.hist[j][4 * ln + 3];
                 const int mine = (int)(c0 + c1 + c2 + c3);
@@ -240,8 +303,10 @@ __device__ __forceinline__ void sweep_tile(const DevTables& T, TileShm<BLOCK>& s
                     sh.rem[j] = rr;
                 }
             }
-            __syncthreads();
         }
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < TC; j++) { thr[j] = sh.prefix[j]; below[j] = T.inlierNum - 1 - sh.rem[j]; }   // rem = rank among the copies of thr
     }
     // ---- sums in fp64 (order-free), float at the end; one cube at a time to keep registers low
     const int wave = tid >> 6, lane = tid & 63;
@@ -249,12 +314,12 @@ __device__ __forceinline__ void sweep_tile(const DevTables& T, TileShm<BLOCK>& s
     for (int j = 0; j < TC; j++) {
         double aub = 0.0, alb = 0.0;
         const float mtd = sh.mtd[j];
-        const unsigned thr = sh.prefix[j];
+        const unsigned thrj = thr[j];
 #pragma unroll
         for (int m = 0; m < PPT; m++) {
             if (tid + m * BLOCK < Nd) {
                 const float d = r[j][m];
-                const bool in = !T.doTrim || __float_as_uint(d) < thr;
+                const bool in = !T.doTrim || __float_as_uint(d) < thrj;
                 if (in) {
                     const float e = d - mtd;
                     if (T.norm == 2) { aub += (double)(d * d); if (e > 0.f) alb += (double)(e * e); }
@@ -266,18 +331,22 @@ __device__ __forceinline__ void sweep_tile(const DevTables& T, TileShm<BLOCK>& s
         if (lane == 0) { sh.red[wave][2 * j] = u; sh.red[wave][2 * j + 1] = l; }
     }
     __syncthreads();
-    if (tid < TC) {
-        double u = 0.0, l = 0.0;
-        for (int w = 0; w < BLOCK / 64; w++) { u += sh.red[w][2 * tid]; l += sh.red[w][2 * tid + 1]; }
-        if (T.doTrim) {
-            // the (rem+1) copies of the threshold value that belong to the inlier set
-            float d = __uint_as_float(sh.prefix[tid]);
-            float e = d - sh.mtd[tid];
-            double n = (double)(sh.rem[tid] + 1);
-            if (T.norm == 2) { u += n * (double)(d * d); if (e > 0.f) l += n * (double)(e * e); }
-            else if (T.norm == 1) { u += n * (double)d; if (e > 0.f) l += n * (double)e; }
+    // every lane holds thr[]/below[] (wave-uniform); lane j finishes cube j
+#pragma unroll
+    for (int j = 0; j < TC; j++) {
+        if (tid == j) {
+            double u = 0.0, l = 0.0;
+            for (int w = 0; w < BLOCK / 64; w++) { u += sh.red[w][2 * j]; l += sh.red[w][2 * j + 1]; }
+            if (T.doTrim) {
+                // the copies of the threshold value that belong to the inlier set
+                const float d = __uint_as_float(thr[j]);
+                const float e = d - sh.mtd[j];
+                const double n = (double)(T.inlierNum - below[j]);
+                if (T.norm == 2) { u += n * (double)(d * d); if (e > 0.f) l += n * (double)(e * e); }
+                else if (T.norm == 1) { u += n * (double)d; if (e > 0.f) l += n * (double)e; }
+            }
+            sh.ub[j] = (float)u; sh.lb[j] = (float)l;
         }
-        sh.ub[tid] = (float)u; sh.lb[tid] = (float)l;
     }
     __syncthreads();
 }
@@ -379,17 +448,20 @@ __global__ __launch_bounds__(BLOCK) void k_inner_bnb(DevTables T, const goicp_bn
     // K5 fused: pDataTemp = R*p, float, left to right (reference jly_goicp.cpp:750-756)
     float px[PPT], py[PPT], pz[PPT], pw[PPT], prho[PPT];
     const bool use_rho = job.rot_level >= 0;
+    {
+        float x[PPT], y[PPT], z[PPT], rh[PPT];
+        const float* rho_row = T.maxRotDis + (size_t)(use_rho ? job.rot_level : 0) * Nd;
 #pragma unroll
-    for (int m = 0; m < PPT; m++) {
-        const int i = tid + m * BLOCK;
-        px[m] = py[m] = pz[m] = 0.f; pw[m] = 0.f; prho[m] = 0.f;
-        if (i < Nd) {
-            const float x = T.dxyz[3 * i], y = T.dxyz[3 * i + 1], z = T.dxyz[3 * i + 2];
-            px[m] = job.R[0] * x + job.R[1] * y + job.R[2] * z;
-            py[m] = job.R[3] * x + job.R[4] * y + job.R[5] * z;
-            pz[m] = job.R[6] * x + job.R[7] * y + job.R[8] * z;
-            pw[m] = T.weights[i];
-            if (use_rho) prho[m] = T.maxRotDis[(size_t)job.rot_level * Nd + i];
+        for (int m = 0; m < PPT; m++) {
+            const int i = min(tid + m * BLOCK, Nd - 1);
+            x[m] = T.dxyz[3 * i]; y[m] = T.dxyz[3 * i + 1]; z[m] = T.dxyz[3 * i + 2]; pw[m] = T.weights[i]; rh[m] = rho_row[i];
+        }
+#pragma unroll
+        for (int m = 0; m < PPT; m++) {
+            px[m] = job.R[0] * x[m] + job.R[1] * y[m] + job.R[2] * z[m];
+            py[m] = job.R[3] * x[m] + job.R[4] * y[m] + job.R[5] * z[m];
+            pz[m] = job.R[6] * x[m] + job.R[7] * y[m] + job.R[8] * z[m];
+            prho[m] = use_rho ? rh[m] : 0.f;
         }
     }
 
@@ -488,15 +560,13 @@ __global__ __launch_bounds__(BLOCK) void k_eval_cubes(DevTables T, const float4*
     float* fpbuf = fpscratch ? fpscratch + (size_t)blockIdx.x * NLMAX * Nd : nullptr;
     float px[PPT], py[PPT], pz[PPT], pw[PPT], prho[PPT];
     const bool use_rho = rot_level >= 0;
+    {   // all loads first (clamped index instead of a branch), one wait for the lot
+        float4 p[PPT]; float rh[PPT];
+        const float* rho_row = T.maxRotDis + (size_t)(use_rho ? rot_level : 0) * Nd;
 #pragma unroll
-    for (int m = 0; m < PPT; m++) {
-        const int i = tid + m * BLOCK;
-        px[m] = py[m] = pz[m] = 0.f; pw[m] = 0.f; prho[m] = 0.f;
-        if (i < Nd) {
-            float4 p = rot[i];
-            px[m] = p.x; py[m] = p.y; pz[m] = p.z; pw[m] = p.w;
-            if (use_rho) prho[m] = T.maxRotDis[(size_t)rot_level * Nd + i];
-        }
+        for (int m = 0; m < PPT; m++) { const int i = min(tid + m * BLOCK, Nd - 1); p[m] = rot[i]; rh[m] = rho_row[i]; }
+#pragma unroll
+        for (int m = 0; m < PPT; m++) { px[m] = p[m].x; py[m] = p[m].y; pz[m] = p[m].z; pw[m] = p[m].w; prho[m] = use_rho ? rh[m] : 0.f; }
     }
     if (tid < TC) {
         const int j = tid, c = min(base + j, n - 1);          // the tail tile re-evaluates the last cube
@@ -710,6 +780,7 @@ extern "C" int goicp_engine_create(const goicp_engine_desc* d, goicp_engine** ou
     if (d->cfpfh == 1) { T.b0 = 0; T.b1 = 41; } else if (d->cfpfh == 2) { T.b0 = 0; T.b1 = 33; } else if (d->cfpfh == 3) { T.b0 = 33; T.b1 = 41; }
     T.reg = d->regularization; T.regFPFH = d->regularizationFPFH;
     T.use_compat = use_compat; T.use_fpfh = use_fpfh;
+    { const char* e = getenv("GOICP_DBG"); T.dbg = e ? atoi(e) : 0; }
     T.exact = (d->parity_mode && d->Nd <= 1536) ? 1 : 0;   // TC*Nd floats of LDS next to the static tile state
     const size_t ncell = (size_t)d->S * d->S * d->S;
     float* p_dist; CR(dev_upload(h, d->dt_dist, ncell, &p_dist)); T.dist = p_dist;
@@ -782,6 +853,16 @@ extern "C" int goicp_engine_create(const goicp_engine_desc* d, goicp_engine** ou
     CR(dev_upload<float>(h, nullptr, h->lat_cap, &h->d_fp));
     pick_geometry(h);
     if (h->dyn_lds + sizeof(TileShm<1024>) + 64 > 160 * 1024) { h->err = "LDS budget exceeded"; CR(GOICP_ERR_ARG); }
+    if (h->dyn_lds) {
+        // static tile state + the parity-mode residual rows can exceed the 64 KB a launch gets without asking
+#define SETATTR(B, P) do { CRH(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_inner_bnb<B, P>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->dyn_lds)); \
+                           CRH(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_eval_cubes<B, P>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->dyn_lds)); } while (0)
+        if (h->block == 256 && h->ppt == 1) SETATTR(256, 1);
+        else if (h->block == 256 && h->ppt == 2) SETATTR(256, 2);
+        else if (h->block == 1024 && h->ppt == 1) SETATTR(1024, 1);
+        else if (h->block == 1024 && h->ppt == 2) SETATTR(1024, 2);
+#undef SETATTR
+    }
 #undef CR
 #undef CRH
     *out = h;
