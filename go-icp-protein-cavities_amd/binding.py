@@ -157,6 +157,11 @@ class Engine:
     def eval_cubes_dev(self, slot, level, cubes_ptr, n, ub_ptr, lb_ptr):
         self._chk(self.L.goicp_engine_eval_cubes_dev(self.h, int(slot), int(level), C.c_void_p(cubes_ptr), int(n), C.c_void_p(ub_ptr), C.c_void_p(lb_ptr)), "eval_cubes_dev")
 
+    def eval_cubes_multi_dev(self, slots, levels, cubes_ptr, n, ub_ptr, lb_ptr):
+        slots = _i32(slots); levels = _i32(levels)
+        self._chk(self.L.goicp_engine_eval_cubes_multi_dev(self.h, _ptr(slots), _ptr(levels), len(slots), C.c_void_p(cubes_ptr), int(n),
+                                                           C.c_void_p(ub_ptr), C.c_void_p(lb_ptr)), "eval_cubes_multi_dev")
+
     def corner_terms(self, slot, xyz):
         xyz = np.ascontiguousarray(xyz, dtype=np.float32).reshape(-1, 3)
         n = len(xyz); cnt = np.zeros(n, np.int32); fp = np.zeros(n, np.float32)

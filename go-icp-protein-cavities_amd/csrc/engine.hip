@@ -79,6 +79,17 @@ __device__ __forceinline__ unsigned dt_index(const DevTables& T, float X, float 
     if ((ax | ay | az) != 0) { const float a = (float)ax, b = (float)ay, c = (float)az; ext = sqrtf(a * a + b * b + c * c); }
     return (unsigned)((z * S + y) * S + x);
 }
+// one axis of dt_index(): clamped cell coordinate and signed out-of-grid offset
+__device__ __forceinline__ int dt_axis(float v, double mn, double scale, int S, int& off) {
+    const int x = cell_of(v, mn, scale);
+    off = x < 0 ? x : (x >= S ? x - S + 1 : 0);
+    return min(max(x, 0), S - 1);
+}
+__device__ __forceinline__ float dt_ext(int ax, int ay, int az) {
+    float ext = 0.f;
+    if ((ax | ay | az) != 0) { const float a = (float)ax, b = (float)ay, c = (float)az; ext = sqrtf(a * a + b * b + c * c); }
+    return ext;
+}
 __device__ __forceinline__ float dt_finish(const DevTables& T, float v, float ext) {
     if (ext > 0.f) v = (float)((double)ext / T.scale + (double)v);      // float sqrt, double divide and add, rounded to float
     return v;
@@ -155,7 +166,7 @@ struct TileShm {
 // Evaluate the TC cubes whose descriptors sit in sh.cube[] against the PPT points each lane holds in
 // registers. Results: sh.ub[], sh.lb[] (geometric part only; the penalty part is added by the caller).
 // Restates reference jly_goicp.cpp:343-415.
-template <int BLOCK, int PPT>
+template <int BLOCK, int PPT, bool OCT>
 __device__ __forceinline__ void sweep_tile(const DevTables& T, TileShm<BLOCK>& sh, const float (&px)[PPT], const float (&py)[PPT],
                                            const float (&pz)[PPT], const float (&pw)[PPT], const float (&prho)[PPT], bool use_rho,
                                            float* rbuf /* LDS, exact mode only */) {
@@ -167,8 +178,25 @@ __device__ __forceinline__ void sweep_tile(const DevTables& T, TileShm<BLOCK>& s
 #pragma unroll
     for (int m = 0; m < PPT; m++) {
         unsigned idx[TC]; float ext[TC], v[TC];
+        if (OCT) {
+            // the 8 cubes are the 2x2x2 children of one node: child j sits at (j&1, j>>1&1, j>>2&1), so only two distinct
+            // centre coordinates exist per axis and the (double) cell arithmetic is done 6 times instead of 24
+            int cx[2], cy[2], cz[2], ox[2], oy[2], oz[2];
 #pragma unroll
-        for (int j = 0; j < TC; j++) idx[j] = dt_index(T, px[m] + sh.cen[j][0], py[m] + sh.cen[j][1], pz[m] + sh.cen[j][2], ext[j]);
+            for (int q = 0; q < 2; q++) {
+                cx[q] = dt_axis(px[m] + sh.cen[q][0], T.xMin, T.scale, T.S, ox[q]);
+                cy[q] = dt_axis(py[m] + sh.cen[2 * q][1], T.yMin, T.scale, T.S, oy[q]);
+                cz[q] = dt_axis(pz[m] + sh.cen[4 * q][2], T.zMin, T.scale, T.S, oz[q]);
+            }
+#pragma unroll
+            for (int j = 0; j < TC; j++) {
+                idx[j] = (unsigned)((cz[j >> 2 & 1] * T.S + cy[j >> 1 & 1]) * T.S + cx[j & 1]);
+                ext[j] = dt_ext(ox[j & 1], oy[j >> 1 & 1], oz[j >> 2 & 1]);
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < TC; j++) idx[j] = dt_index(T, px[m] + sh.cen[j][0], py[m] + sh.cen[j][1], pz[m] + sh.cen[j][2], ext[j]);
+        }
 #pragma unroll
         for (int j = 0; j < TC; j++) v[j] = T.dist[(T.dbg & 2) ? (idx[j] & 1023u) : idx[j]];
 #pragma unroll
@@ -511,7 +539,7 @@ __global__ __launch_bounds__(BLOCK) void k_inner_bnb(DevTables T, const goicp_bn
             sh.lat[l][2] = az == 0 ? parent.z : (az == 1 ? z1 : z1 + w);
         }
         __syncthreads();
-        sweep_tile<BLOCK, PPT>(T, sh, px, py, pz, pw, prho, use_rho, rbuf);
+        sweep_tile<BLOCK, PPT, true>(T, sh, px, py, pz, pw, prho, use_rho, rbuf);
         if (penalties) lattice_terms<BLOCK, PPT>(T, sh, 27, px, py, pz, fpbuf);
         if (tid == 0) {
             cubes += 8;
@@ -549,7 +577,8 @@ __global__ __launch_bounds__(BLOCK) void k_inner_bnb(DevTables T, const goicp_bn
 // k_eval_cubes: 8 free cubes per workgroup; cloud = rotation slot prepared by k_rotate
 // ---------------------------------------------------------------------------------------------
 template <int BLOCK, int PPT>
-__global__ __launch_bounds__(BLOCK) void k_eval_cubes(DevTables T, const float4* __restrict__ rot /*[Nd] x,y,z,weight*/, int rot_level,
+__global__ __launch_bounds__(BLOCK) void k_eval_cubes(DevTables T, const float4* __restrict__ rot_all /*[slots][Nd] x,y,z,weight*/, int slot0, int level0,
+                                                       const int2* __restrict__ groups /* (slot, rot_level) per blockIdx.y, or null */,
                                                        const float* __restrict__ cubes, int n, float* __restrict__ ub_out, float* __restrict__ lb_out,
                                                        float* fpscratch) {
     __shared__ TileShm<BLOCK> sh;
@@ -557,7 +586,12 @@ __global__ __launch_bounds__(BLOCK) void k_eval_cubes(DevTables T, const float4*
     const int tid = threadIdx.x;
     const int Nd = T.Nd;
     const int base = blockIdx.x * TC;
-    float* fpbuf = fpscratch ? fpscratch + (size_t)blockIdx.x * NLMAX * Nd : nullptr;
+    // one launch can sweep the same cube list for many (rotation, rho-level) pairs: blockIdx.y picks the pair
+    int slot = slot0, rot_level = level0;
+    if (groups) { const int2 g = groups[blockIdx.y]; slot = g.x; rot_level = g.y; }
+    const float4* __restrict__ rot = rot_all + (size_t)slot * Nd;
+    ub_out += (size_t)blockIdx.y * n; lb_out += (size_t)blockIdx.y * n;
+    float* fpbuf = fpscratch ? fpscratch + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * NLMAX * Nd : nullptr;
     float px[PPT], py[PPT], pz[PPT], pw[PPT], prho[PPT];
     const bool use_rho = rot_level >= 0;
     {   // all loads first (clamped index instead of a branch), one wait for the lot
@@ -584,7 +618,7 @@ __global__ __launch_bounds__(BLOCK) void k_eval_cubes(DevTables T, const float4*
         sh.lat[tid][2] = sh.cube[j][2] + (c >> 2 & 1) * sh.cube[j][3];
     }
     __syncthreads();
-    sweep_tile<BLOCK, PPT>(T, sh, px, py, pz, pw, prho, use_rho, rbuf);
+    sweep_tile<BLOCK, PPT, false>(T, sh, px, py, pz, pw, prho, use_rho, rbuf);
     if (penalties) lattice_terms<BLOCK, PPT>(T, sh, 8 * TC, px, py, pz, fpbuf);
     if (tid < TC && base + tid < n) {
         const int j = tid;
@@ -694,7 +728,7 @@ struct goicp_engine {
     goicp_bnb_job* d_jobs; goicp_bnb_result* d_results; int job_cap;
     HeapNode* d_heaps; int heap_cap; size_t heap_jobs;
     float* d_fpscratch; size_t fp_blocks;
-    float* d_cubes; float* d_ub; float* d_lb; int cube_cap;
+    float* d_cubes; float* d_ub; float* d_lb; int cube_cap; int2* d_groups;
     double* d_Rt; float* d_Rtf; float* d_dist; int* d_int; float* d_lat; int lat_cap; int* d_cnt; float* d_fp;
     int block, ppt; size_t dyn_lds;
     unsigned max_pops;
@@ -839,6 +873,7 @@ extern "C" int goicp_engine_create(const goicp_engine_desc* d, goicp_engine** ou
     h->job_cap = 4096;
     CR(dev_upload<goicp_bnb_job>(h, nullptr, h->job_cap, &h->d_jobs));
     CR(dev_upload<goicp_bnb_result>(h, nullptr, h->job_cap, &h->d_results));
+    CR(dev_upload<int2>(h, nullptr, 4096, &h->d_groups));
     h->cube_cap = 1 << 16;
     CR(dev_upload<float>(h, nullptr, (size_t)4 * h->cube_cap, &h->d_cubes));
     CR(dev_upload<float>(h, nullptr, h->cube_cap, &h->d_ub));
@@ -916,20 +951,38 @@ static int ensure_fpscratch(goicp_engine* h, size_t blocks) {
         else { CALL(512, 16); }                                              \
     } while (0)
 
+static int launch_eval(goicp_engine* h, int slot, int rot_level, const int2* groups_dev, int ngroups, const void* cubes_dev, int n, void* ub_dev, void* lb_dev) {
+    const int tiles = (n + TC - 1) / TC;
+    int rc = ensure_fpscratch(h, (size_t)tiles * ngroups);
+    if (rc != GOICP_OK) return rc;
+#define CALL(B, P) hipLaunchKernelGGL((k_eval_cubes<B, P>), dim3(tiles, ngroups), dim3(B), h->dyn_lds, h->stream, h->T, h->d_rot, slot, rot_level, groups_dev, (const float*)cubes_dev, n, (float*)ub_dev, (float*)lb_dev, h->d_fpscratch)
+    DISPATCH_GEOM(h, CALL);
+#undef CALL
+    HIPCHK(h, hipGetLastError());
+    h->n_cubes += (uint64_t)n * ngroups; h->n_lookups += (uint64_t)n * ngroups * h->T.Nd;
+    return GOICP_OK;
+}
+
 extern "C" int goicp_engine_eval_cubes_dev(goicp_engine* h, int slot, int rot_level, const void* cubes_dev, int n, void* ub_dev, void* lb_dev) {
     if (!h || slot < 0 || slot >= h->nslots || rot_level >= GOICP_MAXROTLEVEL || n < 0 || (n && (!cubes_dev || !ub_dev || !lb_dev))) return GOICP_ERR_ARG;
     if (n == 0) return GOICP_OK;
     HIPCHK(h, hipSetDevice(h->device));
-    const int tiles = (n + TC - 1) / TC;
-    int rc = ensure_fpscratch(h, (size_t)tiles);
-    if (rc != GOICP_OK) return rc;
-    const float4* rot = h->d_rot + (size_t)slot * h->T.Nd;
-#define CALL(B, P) hipLaunchKernelGGL((k_eval_cubes<B, P>), dim3(tiles), dim3(B), h->dyn_lds, h->stream, h->T, rot, rot_level, (const float*)cubes_dev, n, (float*)ub_dev, (float*)lb_dev, h->d_fpscratch)
-    DISPATCH_GEOM(h, CALL);
-#undef CALL
-    HIPCHK(h, hipGetLastError());
-    h->n_cubes += (uint64_t)n; h->n_lookups += (uint64_t)n * h->T.Nd;
-    return GOICP_OK;
+    return launch_eval(h, slot, rot_level, nullptr, 1, cubes_dev, n, ub_dev, lb_dev);
+}
+
+extern "C" int goicp_engine_eval_cubes_multi_dev(goicp_engine* h, const int32_t* slots, const int32_t* rot_levels, int ngroups,
+                                                 const void* cubes_dev, int n, void* ub_dev, void* lb_dev) {
+    if (!h || !slots || !rot_levels || ngroups <= 0 || ngroups > 4096 || n < 0 || (n && (!cubes_dev || !ub_dev || !lb_dev))) return GOICP_ERR_ARG;
+    if (n == 0) return GOICP_OK;
+    std::vector<int2> g((size_t)ngroups);
+    for (int k = 0; k < ngroups; k++) {
+        if (slots[k] < 0 || slots[k] >= h->nslots || rot_levels[k] >= GOICP_MAXROTLEVEL) return GOICP_ERR_ARG;
+        g[k].x = slots[k]; g[k].y = rot_levels[k];
+    }
+    HIPCHK(h, hipSetDevice(h->device));
+    HIPCHK(h, hipMemcpyAsync(h->d_groups, g.data(), (size_t)ngroups * sizeof(int2), hipMemcpyHostToDevice, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));     // g is a stack-lifetime staging buffer
+    return launch_eval(h, 0, -1, h->d_groups, ngroups, cubes_dev, n, ub_dev, lb_dev);
 }
 
 extern "C" int goicp_engine_eval_cubes(goicp_engine* h, int slot, int rot_level, const float* cubes, int n, float* ub, float* lb) {

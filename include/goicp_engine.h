@@ -110,6 +110,9 @@ int goicp_engine_num_slots(const goicp_engine* h);
 int goicp_engine_eval_cubes(goicp_engine* h, int slot, int rot_level, const float* cubes, int n, float* ub, float* lb);
 /* same on device-resident buffers, asynchronous on the engine's stream (bench / pipelines) */
 int goicp_engine_eval_cubes_dev(goicp_engine* h, int slot, int rot_level, const void* cubes_dev, int n, void* ub_dev, void* lb_dev);
+/* one launch for ngroups (rotation slot, rot_level) pairs over the same n cubes; ub/lb are [ngroups][n] on the device */
+int goicp_engine_eval_cubes_multi_dev(goicp_engine* h, const int32_t* slots, const int32_t* rot_levels, int ngroups,
+                                      const void* cubes_dev, int n, void* ub_dev, void* lb_dev);
 /* per-lattice-point penalty terms at n translations (x,y,z triplets): incompatibility counts and c-FPFH means */
 int goicp_engine_corner_terms(goicp_engine* h, int slot, const float* xyz, int n, int32_t* incompat, float* fpfh);
 

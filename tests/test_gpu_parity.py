@@ -203,6 +203,24 @@ def test_synthetic_cloud_against_oracle(n, S, trim):
     e.close()
 
 
+def test_multi_group_launch_equals_single_launches():
+    H = load_hotpath("pair1_default"); P = load_clouds("pair1")
+    import torch
+    e = engine_from_hotpath(H, P)
+    for s in range(4):
+        e.set_rotation(s, H["call_R"][s])
+    cubes = H["cubes"][:200, 1:5].astype(np.float32).copy()
+    slots = np.array([0, 1, 2, 3, 1], np.int32); levels = np.array([-1, 2, 5, -1, 0], np.int32)
+    dc = torch.from_numpy(cubes).cuda(); ub = torch.zeros((5, len(cubes)), device="cuda"); lb = torch.zeros_like(ub)
+    e.eval_cubes_multi_dev(slots, levels, dc.data_ptr(), len(cubes), ub.data_ptr(), lb.data_ptr())
+    e.synchronize()
+    ub = ub.cpu().numpy(); lb = lb.cpu().numpy()
+    for g in range(5):
+        u1, l1 = e.eval_cubes(int(slots[g]), int(levels[g]), cubes)
+        assert np.array_equal(ub[g], u1) and np.array_equal(lb[g], l1)
+    e.close()
+
+
 def test_full_size_properties_300_cubed():
     """BASELINE config-3 shape (N=5000, 300^3 DT, trim 0.1): size-independent properties of the cube sweep.
     (i) a cube evaluated alone == the same cube inside a large batch; (ii) lb <= ub; (iii) bounds are monotone in
