@@ -168,7 +168,7 @@ def main():
 
     if rank == 0:
         traffic = None
-        pj = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
+        pj = os.path.join(ROOT, "profiles", "r01_summary.json")
         if os.path.exists(pj):
             try:
                 traffic = json.load(open(pj)).get("hbm_bytes_per_launch")

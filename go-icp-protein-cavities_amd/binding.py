@@ -46,7 +46,7 @@ class _Desc(C.Structure):
 
 class BnbJob(C.Structure):
     _fields_ = [("R", C.c_float * 9), ("rot_level", C.c_int32), ("optError_in", C.c_float), ("SSEThresh", C.c_float),
-                ("init", C.c_float * 4), ("init_lb", C.c_float)]
+                ("init", C.c_float * 4), ("init_lb", C.c_float), ("max_pops", C.c_uint32)]
 
 
 class BnbResult(C.Structure):
@@ -179,7 +179,7 @@ class Engine:
             J[i].rot_level = int(j["level"]); J[i].optError_in = float(j["E"]); J[i].SSEThresh = float(j["sse"])
             for k in range(4):
                 J[i].init[k] = float(j["init"][k])
-            J[i].init_lb = float(j.get("init_lb", 0.0))
+            J[i].init_lb = float(j.get("init_lb", 0.0)); J[i].max_pops = int(j.get("max_pops", 0))
         rc = self.L.goicp_engine_inner_bnb_batch(self.h, J, n, Rr)
         self._chk(rc, "inner_bnb_batch")
         return [dict(val=np.float32(r.optErrorT), node=np.array(list(r.node), np.float32), found=int(r.found), status=int(r.status),
@@ -215,7 +215,7 @@ class Engine:
 class GoICP:
     """Registration-level surface (GoICP::BuildDT / Register) through include/goicp_c.h."""
 
-    def __init__(self, cfgvec=None, device_id=0, parity_mode=1, speculate=1, verbose=0):
+    def __init__(self, cfgvec=None, device_id=0, parity_mode=1, speculate=8, verbose=0):
         self.L = load_library()
         self.h = C.c_void_p(self.L.goicp_new())
         self.Nd = self.Nm = 0

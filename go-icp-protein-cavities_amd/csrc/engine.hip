@@ -53,6 +53,7 @@ struct DevTables {
     float reg, regFPFH;
     int use_compat, use_fpfh, exact;
     int dbg;                 // GOICP_DBG ablation bits (diagnosis only; results are wrong when set)
+    unsigned long long* dbg_times;   // [8] per-phase cycle sums of job 0, lane 0 (GOICP_DBG & 32)
 };
 
 struct HeapNode { float x, y, z, w, ub, lb; };
@@ -383,10 +384,10 @@ __device__ __forceinline__ void sweep_tile(const DevTables& T, TileShm<BLOCK>& s
 // jly_goicp.cpp:919-928) into sh.cnt[], c-FPFH means (sumFPFH, jly_goicp.cpp:1689-1697) into sh.fpv[].
 template <int BLOCK, int PPT>
 __device__ __forceinline__ void lattice_terms(const DevTables& T, TileShm<BLOCK>& sh, int nl, const float (&px)[PPT], const float (&py)[PPT],
-                                              const float (&pz)[PPT], float* fpbuf /* global scratch [NLMAX*Nd] */) {
+                                              const float (&pz)[PPT], float* fpbuf /* global scratch [NLMAX*Nd] */, bool do_compat = true) {
     const int tid = threadIdx.x, lane = tid & 63;
     const int Nd = T.Nd;
-    if (T.use_compat) {
+    if (T.use_compat && do_compat) {
         for (int l = tid; l < nl; l += BLOCK) sh.cnt[l] = 0;
         __syncthreads();
         unsigned cls[PPT];
@@ -430,29 +431,78 @@ __device__ __forceinline__ void lattice_terms(const DevTables& T, TileShm<BLOCK>
     }
 }
 
+// Incompatibility counts at the 27 points of the 3x3x3 corner lattice of a node's children (k_inner_bnb).
+// Lattice point l = a + 3b + 9c has coordinates (X[a], Y[b], Z[c]), so the (double) cell arithmetic is done 9 times
+// per data point instead of 81, and the 27 mask gathers of a point are issued together before any of them is used.
+template <int BLOCK, int PPT>
+__device__ __forceinline__ void lattice_compat_oct(const DevTables& T, TileShm<BLOCK>& sh, const float (&px)[PPT], const float (&py)[PPT], const float (&pz)[PPT]) {
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int Nd = T.Nd, S = T.S;
+    if (tid < 27) sh.cnt[tid] = 0;
+    __syncthreads();
+    int wc[27];
+#pragma unroll
+    for (int l = 0; l < 27; l++) wc[l] = 0;
+#pragma unroll
+    for (int m = 0; m < PPT; m++) {
+        const int i = min(tid + m * BLOCK, Nd - 1);
+        const bool valid = tid + m * BLOCK < Nd;
+        const unsigned cls = (unsigned)T.dcls[i];
+        int cx[3], cy[3], cz[3];
+#pragma unroll
+        for (int a = 0; a < 3; a++) {
+            cx[a] = min(max(cell_of(px[m] + sh.lat[a][0], T.xMin, T.scale), 0), S - 1);
+            cy[a] = min(max(cell_of(py[m] + sh.lat[3 * a][1], T.yMin, T.scale), 0), S - 1);
+            cz[a] = min(max(cell_of(pz[m] + sh.lat[9 * a][2], T.zMin, T.scale), 0), S - 1);
+        }
+        unsigned mk[27];
+#pragma unroll
+        for (int l = 0; l < 27; l++) mk[l] = T.cmask[(size_t)((cz[l / 9] * S + cy[(l / 3) % 3]) * S + cx[l % 3])];
+#pragma unroll
+        for (int l = 0; l < 27; l++) wc[l] += __popcll(__ballot(valid && ((mk[l] >> cls) & 1u) == 0u));
+    }
+    if (lane == 0) {
+#pragma unroll
+        for (int l = 0; l < 27; l++) if (wc[l]) atomicAdd(&sh.cnt[l], wc[l]);
+    }
+    __syncthreads();
+}
+
 // ---------------------------------------------------------------------------------------------
 // binary heap with the element order of std::priority_queue<TRANSNODE> (reference jly_goicp.h:75-87):
 // the hole is sifted to a leaf along the not-lower child, then the displaced value is sifted up.
 // ---------------------------------------------------------------------------------------------
 __device__ __forceinline__ bool node_lower(const HeapNode& p, const HeapNode& q) { return p.lb != q.lb ? p.lb > q.lb : p.w < q.w; }
 
-__device__ __forceinline__ void heap_up(HeapNode* a, int hole, const HeapNode& v) {
+// storage: the first `hl` nodes live in LDS (the hot top of the heap), the rest in the job's global slab
+struct HeapStore {
+    HeapNode* lds; HeapNode* glb; int hl;
+    __device__ __forceinline__ HeapNode get(int i) const { return i < hl ? lds[i] : glb[i]; }
+    __device__ __forceinline__ void set(int i, const HeapNode& v) const { if (i < hl) lds[i] = v; else glb[i] = v; }
+};
+__device__ __forceinline__ void heap_up(const HeapStore& a, int hole, const HeapNode& v) {
     int par = (hole - 1) / 2;
-    while (hole > 0 && node_lower(a[par], v)) { a[hole] = a[par]; hole = par; par = (hole - 1) / 2; }
-    a[hole] = v;
+    while (hole > 0) {
+        const HeapNode pn = a.get(par);
+        if (!node_lower(pn, v)) break;
+        a.set(hole, pn); hole = par; par = (hole - 1) / 2;
+    }
+    a.set(hole, v);
 }
-__device__ __forceinline__ void heap_pop(HeapNode* a, int& n) {
+__device__ __forceinline__ void heap_pop(const HeapStore& a, int& n) {
     if (n > 1) {
         const int len = n - 1;
-        HeapNode v = a[len];
-        a[len] = a[0];
+        const HeapNode v = a.get(len);
+        a.set(len, a.get(0));
         int hole = 0, child = 0;
         while (child < (len - 1) / 2) {
             child = 2 * (child + 1);
-            if (node_lower(a[child], a[child - 1])) child--;
-            a[hole] = a[child]; hole = child;
+            HeapNode c1 = a.get(child);
+            const HeapNode c0 = a.get(child - 1);
+            if (node_lower(c1, c0)) { child--; c1 = c0; }
+            a.set(hole, c1); hole = child;
         }
-        if ((len & 1) == 0 && child == (len - 2) / 2) { child = 2 * (child + 1); a[hole] = a[child - 1]; hole = child - 1; }
+        if ((len & 1) == 0 && child == (len - 2) / 2) { child = 2 * (child + 1); a.set(hole, a.get(child - 1)); hole = child - 1; }
         heap_up(a, hole, v);
     }
     n--;
@@ -463,14 +513,15 @@ __device__ __forceinline__ void heap_pop(HeapNode* a, int& n) {
 // ---------------------------------------------------------------------------------------------
 template <int BLOCK, int PPT>
 __global__ __launch_bounds__(BLOCK) void k_inner_bnb(DevTables T, const goicp_bnb_job* __restrict__ jobs, goicp_bnb_result* __restrict__ results,
-                                                      HeapNode* heaps, int heap_cap, float* fpscratch, unsigned max_pops) {
+                                                      HeapNode* heaps, int heap_cap, float* fpscratch, unsigned max_pops, int heap_lds_nodes, int rbuf_floats) {
     __shared__ TileShm<BLOCK> sh;
     __shared__ HeapNode parent;
-    extern __shared__ float rbuf[];
+    extern __shared__ float rbuf[];              // [rbuf_floats] parity-mode residual rows, then the LDS part of the heap
     const int tid = threadIdx.x;
     const int Nd = T.Nd;
     const goicp_bnb_job job = jobs[blockIdx.x];
-    HeapNode* heap = heaps + (size_t)blockIdx.x * heap_cap;
+    HeapStore heap;
+    heap.glb = heaps + (size_t)blockIdx.x * heap_cap; heap.lds = reinterpret_cast<HeapNode*>(rbuf + rbuf_floats); heap.hl = heap_lds_nodes;
     float* fpbuf = fpscratch ? fpscratch + (size_t)blockIdx.x * NLMAX * Nd : nullptr;
 
     // K5 fused: pDataTemp = R*p, float, left to right (reference jly_goicp.cpp:750-756)
@@ -500,24 +551,28 @@ __global__ __launch_bounds__(BLOCK) void k_inner_bnb(DevTables T, const goicp_bn
     unsigned pops = 0, cubes = 0;
     if (tid == 0) {
         HeapNode root; root.x = job.init[0]; root.y = job.init[1]; root.z = job.init[2]; root.w = job.init[3]; root.ub = 0.f; root.lb = job.init_lb;
-        heap[0] = root; hn = 1;
+        heap.set(0, root); hn = 1;
     }
     const bool penalties = T.use_compat || T.use_fpfh;
+    const bool timing = (T.dbg & 32) && T.dbg_times && blockIdx.x == 0 && tid == 0;
+    unsigned long long tph[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tlast = timing ? clock64() : 0ull;
+#define STAMP(k) do { if (timing) { const unsigned long long now_ = clock64(); tph[k] += now_ - tlast; tlast = now_; } } while (0)
 
     for (;;) {
         if (tid == 0) {
             int done = 0;
             if (hn == 0) done = 1;
             else {
-                parent = heap[0];
+                parent = heap.get(0);
                 heap_pop(heap, hn);
                 pops++;
                 if (optErrorT - parent.lb < job.SSEThresh) done = 1;          // reference jly_goicp.cpp:317
-                else if (pops > max_pops) { done = 1; status = GOICP_ERR_LIMIT; }
+                else if (pops > (job.max_pops ? job.max_pops : max_pops)) { done = 1; status = GOICP_ERR_LIMIT; }
                 else if (hn + 8 > heap_cap) { done = 1; status = GOICP_ERR_OVERFLOW; }
             }
             sh.ctl[0] = done;
         }
+        STAMP(0);
         __syncthreads();
         if (sh.ctl[0]) break;
         // children (reference jly_goicp.cpp:322-333) and the 3x3x3 lattice of their corners (:436-437,486-488)
@@ -539,8 +594,13 @@ __global__ __launch_bounds__(BLOCK) void k_inner_bnb(DevTables T, const goicp_bn
             sh.lat[l][2] = az == 0 ? parent.z : (az == 1 ? z1 : z1 + w);
         }
         __syncthreads();
+        STAMP(1);
         sweep_tile<BLOCK, PPT, true>(T, sh, px, py, pz, pw, prho, use_rho, rbuf);
-        if (penalties) lattice_terms<BLOCK, PPT>(T, sh, 27, px, py, pz, fpbuf);
+        STAMP(2);
+        if (T.use_compat) lattice_compat_oct<BLOCK, PPT>(T, sh, px, py, pz);
+        STAMP(3);
+        if (T.use_fpfh) lattice_terms<BLOCK, PPT>(T, sh, 27, px, py, pz, fpbuf, false);
+        STAMP(4);
         if (tid == 0) {
             cubes += 8;
             for (int j = 0; j < TC; j++) {
@@ -563,8 +623,11 @@ __global__ __launch_bounds__(BLOCK) void k_inner_bnb(DevTables T, const goicp_bn
                 heap_up(heap, hn - 1, nd);
             }
         }
+        STAMP(5);
         // (the barrier at the top of the next iteration orders lane 0's heap work before anyone reads `parent`)
     }
+    if (timing) { for (int k = 0; k < 8; k++) T.dbg_times[k] += tph[k]; T.dbg_times[7] += pops; }
+#undef STAMP
     if (tid == 0) {
         goicp_bnb_result r;
         r.optErrorT = optErrorT; r.node[0] = bx; r.node[1] = by; r.node[2] = bz; r.node[3] = bw;
@@ -726,11 +789,11 @@ struct goicp_engine {
     // device buffers
     float* d_mxyz; float4* d_rot; float* d_R; int nslots;
     goicp_bnb_job* d_jobs; goicp_bnb_result* d_results; int job_cap;
-    HeapNode* d_heaps; int heap_cap; size_t heap_jobs;
+    HeapNode* d_heaps; int heap_cap; size_t heap_jobs; HeapNode* d_heap_big; int heap_big_cap;
     float* d_fpscratch; size_t fp_blocks;
-    float* d_cubes; float* d_ub; float* d_lb; int cube_cap; int2* d_groups;
+    float* d_cubes; float* d_ub; float* d_lb; int cube_cap; int2* d_groups; std::vector<int2> groups_host;
     double* d_Rt; float* d_Rtf; float* d_dist; int* d_int; float* d_lat; int lat_cap; int* d_cnt; float* d_fp;
-    int block, ppt; size_t dyn_lds;
+    int block, ppt; size_t dyn_lds; size_t dyn_lds_bnb; int heap_lds_nodes; int rbuf_floats;
     unsigned max_pops;
     uint64_t n_cubes, n_lookups; double kernel_ms;
     std::string err;
@@ -760,12 +823,24 @@ extern "C" void goicp_engine_destroy(goicp_engine* h) {
     hipSetDevice(h->device);
     for (void* p : h->allocs) hipFree(p);
     if (h->d_heaps) hipFree(h->d_heaps);
+    if (h->d_heap_big) hipFree(h->d_heap_big);
     if (h->d_fpscratch) hipFree(h->d_fpscratch);
     if (h->ev0) hipEventDestroy(h->ev0);
     if (h->ev1) hipEventDestroy(h->ev1);
     if (h->stream) hipStreamDestroy(h->stream);
     delete h;
 }
+
+#define DISPATCH_GEOM(h, CALL)                                               \
+    do {                                                                     \
+        if (h->block == 256 && h->ppt == 1) { CALL(256, 1); }                \
+        else if (h->block == 256 && h->ppt == 2) { CALL(256, 2); }           \
+        else if (h->block == 1024 && h->ppt == 1) { CALL(1024, 1); }         \
+        else if (h->block == 1024 && h->ppt == 2) { CALL(1024, 2); }         \
+        else if (h->block == 1024 && h->ppt == 4) { CALL(1024, 4); }         \
+        else if (h->block == 1024 && h->ppt == 5) { CALL(1024, 5); }         \
+        else { CALL(512, 16); }                                              \
+    } while (0)
 
 static void pick_geometry(goicp_engine* h) {
     // lanes x points-per-lane; the residuals of a tile (TC x PPT floats per lane) stay in registers across the
@@ -779,6 +854,10 @@ static void pick_geometry(goicp_engine* h) {
     else if (Nd <= 5120) { h->block = 1024; h->ppt = 5; }
     else { h->block = 512; h->ppt = 16; }
     h->dyn_lds = (h->T.exact && !h->T.doTrim) ? (size_t)TC * Nd * sizeof(float) : 0;
+    // k_inner_bnb keeps the top of its queue in LDS behind the residual rows (24 B per node)
+    h->rbuf_floats = (int)(h->dyn_lds / sizeof(float));
+    h->heap_lds_nodes = 2048;
+    h->dyn_lds_bnb = h->dyn_lds + (size_t)h->heap_lds_nodes * sizeof(HeapNode);
 }
 
 extern "C" int goicp_engine_create(const goicp_engine_desc* d, goicp_engine** out) {
@@ -799,7 +878,7 @@ extern "C" int goicp_engine_create(const goicp_engine_desc* d, goicp_engine** ou
     goicp_engine* h = new goicp_engine();
     memset(&h->T, 0, sizeof h->T);
     h->device = d->device_id; h->stream = nullptr; h->ev0 = h->ev1 = nullptr;
-    h->d_heaps = nullptr; h->d_fpscratch = nullptr; h->heap_cap = 0; h->heap_jobs = 0; h->fp_blocks = 0;
+    h->d_heaps = nullptr; h->d_fpscratch = nullptr; h->heap_cap = 8192; h->heap_jobs = 0; h->fp_blocks = 0; h->d_heap_big = nullptr; h->heap_big_cap = 0;
     h->n_cubes = h->n_lookups = 0; h->kernel_ms = 0; h->max_pops = 200000000u;
 #define CR(call) do { int rc_ = (call); if (rc_ != GOICP_OK) { std::string m = h->err; goicp_engine_destroy(h); fprintf(stderr, "goicp_engine_create: %s\n", m.c_str()); return rc_; } } while (0)
 #define CRH(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { fprintf(stderr, "goicp_engine_create: %s: %s\n", #call, hipGetErrorString(e_)); goicp_engine_destroy(h); return GOICP_ERR_NO_DEVICE; } } while (0)
@@ -815,6 +894,7 @@ extern "C" int goicp_engine_create(const goicp_engine_desc* d, goicp_engine** ou
     T.reg = d->regularization; T.regFPFH = d->regularizationFPFH;
     T.use_compat = use_compat; T.use_fpfh = use_fpfh;
     { const char* e = getenv("GOICP_DBG"); T.dbg = e ? atoi(e) : 0; }
+    { const char* e = getenv("GOICP_MAX_POPS"); if (e) h->max_pops = (unsigned)atoll(e); }
     T.exact = (d->parity_mode && d->Nd <= 1536) ? 1 : 0;   // TC*Nd floats of LDS next to the static tile state
     const size_t ncell = (size_t)d->S * d->S * d->S;
     float* p_dist; CR(dev_upload(h, d->dt_dist, ncell, &p_dist)); T.dist = p_dist;
@@ -886,21 +966,26 @@ extern "C" int goicp_engine_create(const goicp_engine_desc* d, goicp_engine** ou
     CR(dev_upload<float>(h, nullptr, (size_t)3 * h->lat_cap, &h->d_lat));
     CR(dev_upload<int>(h, nullptr, h->lat_cap, &h->d_cnt));
     CR(dev_upload<float>(h, nullptr, h->lat_cap, &h->d_fp));
+    { unsigned long long* p_t; CR(dev_upload<unsigned long long>(h, nullptr, 8, &p_t)); CRH(hipMemset(p_t, 0, 64)); T.dbg_times = p_t; }
     pick_geometry(h);
-    if (h->dyn_lds + sizeof(TileShm<1024>) + 64 > 160 * 1024) { h->err = "LDS budget exceeded"; CR(GOICP_ERR_ARG); }
-    if (h->dyn_lds) {
-        // static tile state + the parity-mode residual rows can exceed the 64 KB a launch gets without asking
-#define SETATTR(B, P) do { CRH(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_inner_bnb<B, P>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->dyn_lds)); \
-                           CRH(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_eval_cubes<B, P>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->dyn_lds)); } while (0)
-        if (h->block == 256 && h->ppt == 1) SETATTR(256, 1);
-        else if (h->block == 256 && h->ppt == 2) SETATTR(256, 2);
-        else if (h->block == 1024 && h->ppt == 1) SETATTR(1024, 1);
-        else if (h->block == 1024 && h->ppt == 2) SETATTR(1024, 2);
+    if (h->dyn_lds_bnb + sizeof(TileShm<1024>) + 64 > 160 * 1024) { h->err = "LDS budget exceeded"; CR(GOICP_ERR_ARG); }
+    {
+        // static tile state + residual rows + LDS heap can exceed the 64 KB a launch gets without asking
+#define SETATTR(B, P) do { CRH(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_inner_bnb<B, P>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->dyn_lds_bnb)); \
+                           if (h->dyn_lds) CRH(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_eval_cubes<B, P>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->dyn_lds)); } while (0)
+        DISPATCH_GEOM(h, SETATTR);
 #undef SETATTR
     }
 #undef CR
 #undef CRH
     *out = h;
+    return GOICP_OK;
+}
+
+extern "C" int goicp_engine_debug_times(goicp_engine* h, unsigned long long* out8) {
+    if (!h || !out8) return GOICP_ERR_ARG;
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    HIPCHK(h, hipMemcpy(out8, h->T.dbg_times, 64, hipMemcpyDeviceToHost));
     return GOICP_OK;
 }
 
@@ -940,17 +1025,6 @@ static int ensure_fpscratch(goicp_engine* h, size_t blocks) {
     return GOICP_OK;
 }
 
-#define DISPATCH_GEOM(h, CALL)                                               \
-    do {                                                                     \
-        if (h->block == 256 && h->ppt == 1) { CALL(256, 1); }                \
-        else if (h->block == 256 && h->ppt == 2) { CALL(256, 2); }           \
-        else if (h->block == 1024 && h->ppt == 1) { CALL(1024, 1); }         \
-        else if (h->block == 1024 && h->ppt == 2) { CALL(1024, 2); }         \
-        else if (h->block == 1024 && h->ppt == 4) { CALL(1024, 4); }         \
-        else if (h->block == 1024 && h->ppt == 5) { CALL(1024, 5); }         \
-        else { CALL(512, 16); }                                              \
-    } while (0)
-
 static int launch_eval(goicp_engine* h, int slot, int rot_level, const int2* groups_dev, int ngroups, const void* cubes_dev, int n, void* ub_dev, void* lb_dev) {
     const int tiles = (n + TC - 1) / TC;
     int rc = ensure_fpscratch(h, (size_t)tiles * ngroups);
@@ -980,8 +1054,12 @@ extern "C" int goicp_engine_eval_cubes_multi_dev(goicp_engine* h, const int32_t*
         g[k].x = slots[k]; g[k].y = rot_levels[k];
     }
     HIPCHK(h, hipSetDevice(h->device));
-    HIPCHK(h, hipMemcpyAsync(h->d_groups, g.data(), (size_t)ngroups * sizeof(int2), hipMemcpyHostToDevice, h->stream));
-    HIPCHK(h, hipStreamSynchronize(h->stream));     // g is a stack-lifetime staging buffer
+    if (h->groups_host.size() != g.size() || memcmp(h->groups_host.data(), g.data(), g.size() * sizeof(int2)) != 0) {
+        // new group table: stage it (the staging copy lives in the handle, so no host sync is needed on the launch path)
+        HIPCHK(h, hipStreamSynchronize(h->stream));
+        h->groups_host = g;
+        HIPCHK(h, hipMemcpyAsync(h->d_groups, h->groups_host.data(), (size_t)ngroups * sizeof(int2), hipMemcpyHostToDevice, h->stream));
+    }
     return launch_eval(h, 0, -1, h->d_groups, ngroups, cubes_dev, n, ub_dev, lb_dev);
 }
 
@@ -1023,24 +1101,29 @@ extern "C" int goicp_engine_corner_terms(goicp_engine* h, int slot, const float*
     return GOICP_OK;
 }
 
-static int ensure_heaps(goicp_engine* h, size_t jobs, int cap) {
-    if (h->d_heaps && jobs <= h->heap_jobs && cap <= h->heap_cap) return GOICP_OK;
+static int ensure_heaps(goicp_engine* h, size_t jobs) {
+    // per-job queue slabs of the batch path (fixed capacity; a job that outgrows its slab is re-run alone on the big slab)
+    if (h->d_heaps && jobs <= h->heap_jobs) return GOICP_OK;
     if (h->d_heaps) { HIPCHK(h, hipStreamSynchronize(h->stream)); hipFree(h->d_heaps); h->d_heaps = nullptr; }
-    size_t nj = std::max(jobs, h->heap_jobs);
-    int nc = std::max(cap, h->heap_cap);
-    HIPCHK(h, hipMalloc((void**)&h->d_heaps, nj * (size_t)nc * sizeof(HeapNode)));
-    h->heap_jobs = nj; h->heap_cap = nc;
+    HIPCHK(h, hipMalloc((void**)&h->d_heaps, jobs * (size_t)h->heap_cap * sizeof(HeapNode)));
+    h->heap_jobs = jobs;
     return GOICP_OK;
 }
 
-static int run_bnb(goicp_engine* h, const goicp_bnb_job* jobs, int njobs, goicp_bnb_result* results, int cap) {
-    int rc = ensure_heaps(h, (size_t)njobs, cap);
-    if (rc != GOICP_OK) return rc;
-    rc = ensure_fpscratch(h, (size_t)njobs);
+static int ensure_big_heap(goicp_engine* h, int cap) {
+    if (h->d_heap_big && cap <= h->heap_big_cap) return GOICP_OK;
+    if (h->d_heap_big) { HIPCHK(h, hipStreamSynchronize(h->stream)); hipFree(h->d_heap_big); h->d_heap_big = nullptr; }
+    HIPCHK(h, hipMalloc((void**)&h->d_heap_big, (size_t)cap * sizeof(HeapNode)));
+    h->heap_big_cap = cap;
+    return GOICP_OK;
+}
+
+static int run_bnb(goicp_engine* h, const goicp_bnb_job* jobs, int njobs, goicp_bnb_result* results, HeapNode* heaps, int cap) {
+    int rc = ensure_fpscratch(h, (size_t)njobs);
     if (rc != GOICP_OK) return rc;
     HIPCHK(h, hipMemcpyAsync(h->d_jobs, jobs, (size_t)njobs * sizeof(goicp_bnb_job), hipMemcpyHostToDevice, h->stream));
     HIPCHK(h, hipEventRecord(h->ev0, h->stream));
-#define CALL(B, P) hipLaunchKernelGGL((k_inner_bnb<B, P>), dim3(njobs), dim3(B), h->dyn_lds, h->stream, h->T, h->d_jobs, h->d_results, h->d_heaps, h->heap_cap, h->d_fpscratch, h->max_pops)
+#define CALL(B, P) hipLaunchKernelGGL((k_inner_bnb<B, P>), dim3(njobs), dim3(B), h->dyn_lds_bnb, h->stream, h->T, h->d_jobs, h->d_results, heaps, cap, h->d_fpscratch, h->max_pops, h->heap_lds_nodes, h->rbuf_floats)
     DISPATCH_GEOM(h, CALL);
 #undef CALL
     HIPCHK(h, hipGetLastError());
@@ -1058,15 +1141,20 @@ extern "C" int goicp_engine_inner_bnb_batch(goicp_engine* h, const goicp_bnb_job
     int worst = GOICP_OK;
     for (int off = 0; off < njobs; off += h->job_cap) {
         const int m = std::min(h->job_cap, njobs - off);
-        int rc = run_bnb(h, jobs + off, m, results + off, std::max(h->heap_cap, 8192));
+        int rc = ensure_heaps(h, (size_t)m);
+        if (rc != GOICP_OK) return rc;
+        rc = run_bnb(h, jobs + off, m, results + off, h->d_heaps, h->heap_cap);
         if (rc != GOICP_OK) return rc;
         for (int j = 0; j < m; j++) {
             goicp_bnb_result& r = results[off + j];
-            // a job whose queue outgrew its slab is re-run alone with a larger one (the search is deterministic)
+            // a job whose queue outgrew its slab is re-run alone on a larger one (the search is deterministic); jobs that carry a
+            // pop budget are speculative and are simply reported as overflowed
             int cap = h->heap_cap;
-            while (r.status == GOICP_ERR_OVERFLOW && cap < (1 << 24)) {
+            while (r.status == GOICP_ERR_OVERFLOW && jobs[off + j].max_pops == 0 && cap < (1 << 26)) {
                 cap *= 16;
-                rc = run_bnb(h, jobs + off + j, 1, &r, cap);
+                rc = ensure_big_heap(h, cap);
+                if (rc != GOICP_OK) return rc;
+                rc = run_bnb(h, jobs + off + j, 1, &r, h->d_heap_big, cap);
                 if (rc != GOICP_OK) return rc;
             }
             h->n_cubes += r.cube_evals; h->n_lookups += (uint64_t)r.cube_evals * h->T.Nd;

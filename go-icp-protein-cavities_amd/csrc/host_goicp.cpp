@@ -9,7 +9,10 @@
 #include <cstdio>
 #include <cstring>
 #include <iostream>
+#include <array>
 #include <limits>
+#include <map>
+#include <vector>
 
 #include "goicp.hpp"
 
@@ -434,6 +437,7 @@ static goicp_bnb_job make_job(const float* R9, int level, float E, float sse, co
     std::memcpy(j.R, R9, sizeof j.R);
     j.rot_level = level; j.optError_in = E; j.SSEThresh = sse;
     j.init[0] = init.x; j.init[1] = init.y; j.init[2] = init.z; j.init[3] = init.w; j.init_lb = init.lb;
+    j.max_pops = 0;
     return j;
 }
 
@@ -447,8 +451,37 @@ float GoICP::InnerBnB(const float* R9, int rot_level, TRANSNODE* out) {
     return r.optErrorT;
 }
 
+
+namespace {
+struct PopPlan {
+    ROTNODE ch[8]; float Rj[8][9]; bool live[8];
+    goicp_bnb_result res[16]; goicp_bnb_job job[16]; float res_E[16]; bool have[16];
+};
+typedef std::array<uint32_t, 5> PlanKey;
+PlanKey plan_key(const ROTNODE& n) {
+    PlanKey k; float f[4] = {n.a, n.b, n.c, n.w};
+    for (int i = 0; i < 4; i++) std::memcpy(&k[i], &f[i], 4);
+    k[4] = (uint32_t)n.l;
+    return k;
+}
+// children of a rotation node, their pi-ball test and rotation matrices (reference jly_goicp.cpp:703-747)
+void expand_plan(const ROTNODE& par, PopPlan& pl) {
+    for (int j = 0; j < 8; j++) {
+        ROTNODE& nd = pl.ch[j];
+        nd.w = par.w / 2; nd.l = par.l + 1;
+        nd.a = par.a + (j & 1) * nd.w; nd.b = par.b + (j >> 1 & 1) * nd.w; nd.c = par.c + (j >> 2 & 1) * nd.w;
+        nd.ub = nd.lb = 0;
+        const float v1 = nd.a + nd.w / 2, v2 = nd.b + nd.w / 2, v3 = nd.c + nd.w / 2;
+        pl.live[j] = !((double)std::sqrt(v1 * v1 + v2 * v2 + v3 * v3) - SQRT3 * nd.w / 2 > PI);      // pi-ball skip (:723)
+        if (pl.live[j]) axis_angle(v1, v2, v3, pl.Rj[j]);
+    }
+    for (int k = 0; k < 16; k++) pl.have[k] = false;
+}
+}  // namespace
+
 // reference jly_goicp.cpp:582-876
 float GoICP::OuterBnB() {
+    std::map<PlanKey, PopPlan> plan_cache;
     RotHeap queueRot;
     float lb = 0, ub = 0, error;
     const float nanv = std::numeric_limits<float>::quiet_NaN();
@@ -483,46 +516,70 @@ float GoICP::OuterBnB() {
         queueRot.pop();
         stats.rot_pops++;
         if ((optError - par.lb) <= SSEThresh) break;
-        ROTNODE ch[8]; float Rj[8][9]; bool live[8];
-        for (int j = 0; j < 8; j++) {
-            ROTNODE& nd = ch[j];
-            nd.w = par.w / 2; nd.l = par.l + 1;
-            nd.a = par.a + (j & 1) * nd.w; nd.b = par.b + (j >> 1 & 1) * nd.w; nd.c = par.c + (j >> 2 & 1) * nd.w;
-            nd.ub = nd.lb = 0;
-            const float v1 = nd.a + nd.w / 2, v2 = nd.b + nd.w / 2, v3 = nd.c + nd.w / 2;
-            live[j] = !((double)std::sqrt(v1 * v1 + v2 * v2 + v3 * v3) - SQRT3 * nd.w / 2 > PI);      // pi-ball skip (:723)
-            if (live[j]) axis_angle(v1, v2, v3, Rj[j]);
+        // The 16 InnerBnB calls of a rotation pop (8 children x {ub, lb}) are pure functions of (child rotation, level,
+        // incumbent), so they can be evaluated ahead of time: one launch carries the jobs of this pop AND of the next
+        // `speculate`-1 nodes at the head of the rotation queue. Results are cached per node and consumed strictly in the
+        // reference's order; a result is used only if the incumbent it was computed with is still current and the job ran to
+        // completion (speculative jobs carry a pop budget) -- otherwise it is launched again. Search results are unchanged.
+        PopPlan plan;
+        {
+            auto it = plan_cache.find(plan_key(par));
+            if (it != plan_cache.end()) { plan = it->second; plan_cache.erase(it); }
+            else expand_plan(par, plan);
         }
-        // Speculative batch: the (<=16) InnerBnB calls of this pop are independent searches as long as the incumbent
-        // optError does not change in between, so they are launched together; a result is consumed only if the incumbent
-        // it was computed with is still current, otherwise the rest of the pop is re-launched with the new incumbent.
-        goicp_bnb_result res[16]; goicp_bnb_job res_job[16]; float res_E[16]; bool have[16];
-        for (int k = 0; k < 16; k++) have[k] = false;
-        auto launch_from = [&](int first) -> bool {
-            goicp_bnb_job jobs[16]; int slot[16]; int n = 0;
+        ROTNODE* ch = plan.ch; float (*Rj)[9] = plan.Rj; bool* live = plan.live;
+        auto add_jobs = [&](PopPlan& pl, int first, bool spec, std::vector<goicp_bnb_job>& jobs, std::vector<std::pair<PopPlan*, int>>& where) {
             for (int k = first; k < 16; k++) {
                 const int j = k >> 1;
-                if (!live[j]) continue;
-                jobs[n] = make_job(Rj[j], (k & 1) ? ch[j].l : -1, optError, SSEThresh, initNodeTrans);
-                slot[n++] = k;
-                if (!speculate) break;
+                if (!pl.live[j]) continue;
+                if (pl.have[k] && pl.res_E[k] == optError && pl.res[k].status == GOICP_OK) continue;
+                goicp_bnb_job jb = make_job(pl.Rj[j], (k & 1) ? pl.ch[j].l : -1, optError, SSEThresh, initNodeTrans);
+                if (spec || !jobs.empty()) jb.max_pops = spec_pop_budget;      // only the very first job is certain to be needed as is
+                jobs.push_back(jb); where.emplace_back(&pl, k);
+                if (speculate <= 0) break;
             }
-            if (n == 0) return true;
-            goicp_bnb_result out[16];
-            status = goicp_engine_inner_bnb_batch(eng_, jobs, n, out);
-            stats.inner_launches++; stats.inner_jobs_launched += n;
-            if (status != GOICP_OK) return false;
-            for (int q = 0; q < n; q++) { res[slot[q]] = out[q]; res_job[slot[q]] = jobs[q]; res_E[slot[q]] = optError; have[slot[q]] = true; }
+        };
+        auto launch_from = [&](int first) -> bool {
+            std::vector<goicp_bnb_job> jobs; std::vector<std::pair<PopPlan*, int>> where;
+            add_jobs(plan, first, false, jobs, where);
+            if (speculate > 1 && !queueRot.empty()) {
+                RotHeap peek = queueRot;
+                for (int m = 1; m < speculate && !peek.empty() && (int)jobs.size() + 16 <= 2048; m++) {
+                    const ROTNODE nd = peek.top(); peek.pop();
+                    if ((optError - nd.lb) <= SSEThresh) break;            // the search would stop before expanding it
+                    auto key = plan_key(nd);
+                    auto it = plan_cache.find(key);
+                    if (it == plan_cache.end()) { it = plan_cache.emplace(key, PopPlan()).first; expand_plan(nd, it->second); }
+                    add_jobs(it->second, 0, true, jobs, where);
+                }
+            }
+            if (jobs.empty()) return true;
+            std::vector<goicp_bnb_result> out(jobs.size());
+            const int rc = goicp_engine_inner_bnb_batch(eng_, jobs.data(), (int)jobs.size(), out.data());
+            stats.inner_launches++; stats.inner_jobs_launched += jobs.size();
+            if (rc != GOICP_OK && rc != GOICP_ERR_LIMIT && rc != GOICP_ERR_OVERFLOW) { status = rc; return false; }
+            for (size_t q = 0; q < jobs.size(); q++) {
+                PopPlan& pl = *where[q].first; const int k = where[q].second;
+                pl.res[k] = out[q]; pl.job[k] = jobs[q]; pl.res_E[k] = optError; pl.have[k] = true;
+            }
             return true;
         };
         auto get = [&](int k) -> const goicp_bnb_result* {
-            if (!(have[k] && res_E[k] == optError)) {
-                for (int q = k; q < 16; q++) have[q] = false;
+            if (!(plan.have[k] && plan.res_E[k] == optError && plan.res[k].status == GOICP_OK)) {
+                plan.have[k] = false;
                 if (!launch_from(k)) return nullptr;
+                if (plan.res[k].status != GOICP_OK) {
+                    status = plan.res[k].status;
+                    char buf[160];
+                    snprintf(buf, sizeof buf, "InnerBnB job failed (status %d, rot level %d, incumbent %g, %u pops)", plan.res[k].status, plan.job[k].rot_level,
+                             (double)plan.job[k].optError_in, plan.res[k].pops);
+                    error_message = buf;
+                    return nullptr;
+                }
             }
-            stats.inner_calls++; stats.cube_evals += res[k].cube_evals; stats.trans_pops += res[k].pops;
-            if (record_jobs) { job_log.push_back(res_job[k]); result_log.push_back(res[k]); }
-            return &res[k];
+            stats.inner_calls++; stats.cube_evals += plan.res[k].cube_evals; stats.trans_pops += plan.res[k].pops;
+            if (record_jobs) { job_log.push_back(plan.job[k]); result_log.push_back(plan.res[k]); }
+            return &plan.res[k];
         };
         for (int j = 0; j < 8; j++) {
             if (!live[j]) continue;
@@ -554,6 +611,7 @@ float GoICP::OuterBnB() {
                 RotHeap q2;
                 while (!queueRot.empty()) { const ROTNODE nd = queueRot.top(); queueRot.pop(); if (nd.lb < optError) q2.push(nd); else break; }
                 queueRot = q2;
+                plan_cache.clear();          // every cached result was computed with the old incumbent
             }
             r = get(2 * j + 1);
             if (!r) return nanv;

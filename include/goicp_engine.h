@@ -87,6 +87,7 @@ typedef struct goicp_bnb_job {
     float   SSEThresh;
     float   init[4];       /* initNodeTrans x,y,z,w */
     float   init_lb;       /* initNodeTrans.lb (0 in the reference) */
+    uint32_t max_pops;     /* 0: engine default; else stop with GOICP_ERR_LIMIT after this many queue pops (speculative jobs) */
 } goicp_bnb_job;
 
 typedef struct goicp_bnb_result {

@@ -158,13 +158,16 @@ def test_register_pair2_default_known_answer():
 def test_speculative_batching_does_not_change_the_result():
     G = load_register()["pair1_fpfh33"]; P = load_clouds("pair1")
     outs = []
-    for spec in (0, 1):
+    for spec in (0, 1, 8):
         g = goicp_amd.GoICP(cfg_vector(**G["cfg"])[0], speculate=spec)
         g.set_clouds(P["t"], P["s"], P["tc"], P["sc"], P["tf"], P["sf"]); g.build_dt()
         outs.append(g.register()); g.close()
     assert np.array_equal(outs[0]["R"], outs[1]["R"]) and np.array_equal(outs[0]["t"], outs[1]["t"]) and outs[0]["error"] == outs[1]["error"]
     assert outs[0]["trace"] == outs[1]["trace"]
-    assert outs[1]["stats"]["inner_launches"] < outs[0]["stats"]["inner_launches"]
+    for o in outs[1:]:
+        assert np.array_equal(outs[0]["R"], o["R"]) and np.array_equal(outs[0]["t"], o["t"]) and outs[0]["error"] == o["error"] and outs[0]["trace"] == o["trace"]
+        assert outs[0]["stats"]["trans_pops"] == o["stats"]["trans_pops"]
+    assert outs[2]["stats"]["inner_launches"] < outs[1]["stats"]["inner_launches"] < outs[0]["stats"]["inner_launches"]
 
 
 @pytest.mark.parametrize("n,S,trim", [(1000, 100, 0.0), (1000, 100, 0.1), (5000, 100, 0.1), (3000, 60, 0.0)])
