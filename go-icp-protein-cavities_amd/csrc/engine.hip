@@ -209,26 +209,38 @@ __device__ __forceinline__ void sweep_tile(const DevTables& T, TileShm<BLOCK>& s
         }
     }
     if (T.exact && !T.doTrim) {
-        // reference order: float, sequential over the point index (bit-exact with jly_goicp.cpp:393-415)
+        // reference order: float, sequential over the point index (bit-exact with jly_goicp.cpp:393-415). Every lane first
+        // turns its residuals into the two addends (d*d and max(d-mtd,0)^2, or the norm-1 forms) in parallel; 16 lanes then
+        // run the 16 sequential float sums (8 ub chains, 8 lb chains), one add per element. Skipping a term (e <= 0) and
+        // adding +0.0f leave the same bits because the running sums are never negative.
+        float* tub = rbuf; float* tlb = rbuf + TC * Nd;
+        const bool sq = T.norm == 2, lin = T.norm == 1;
 #pragma unroll
         for (int m = 0; m < PPT; m++) {
             const int i = tid + m * BLOCK;
             if (i < Nd) {
 #pragma unroll
-                for (int j = 0; j < TC; j++) rbuf[j * Nd + i] = r[j][m];
+                for (int j = 0; j < TC; j++) {
+                    const float d = r[j][m], e = d - sh.mtd[j];
+                    tub[j * Nd + i] = sq ? d * d : (lin ? d : 0.f);
+                    tlb[j * Nd + i] = e > 0.f ? (sq ? e * e : (lin ? e : 0.f)) : 0.f;
+                }
             }
         }
         __syncthreads();
-        if (tid < TC) {
-            const float* rr = rbuf + tid * Nd;
-            const float mtd = sh.mtd[tid];
-            float ub = 0.f, lb = 0.f;
-            if (T.norm == 2) {
-                for (int i = 0; i < Nd; i++) { float d = rr[i]; ub += d * d; float e = d - mtd; if (e > 0.f) lb += e * e; }
-            } else if (T.norm == 1) {
-                for (int i = 0; i < Nd; i++) { float d = rr[i]; ub += d; float e = d - mtd; if (e > 0.f) lb += e; }
+        if (tid < 2 * TC) {
+            const float* tt = rbuf + tid * Nd;          // lanes 0-7: ub rows, lanes 8-15: lb rows
+            float acc = 0.f;
+            int i = 0;
+            for (; i + 16 <= Nd; i += 16) {
+                float v[16];
+#pragma unroll
+                for (int q = 0; q < 16; q++) v[q] = tt[i + q];
+#pragma unroll
+                for (int q = 0; q < 16; q++) acc += v[q];
             }
-            sh.ub[tid] = ub; sh.lb[tid] = lb;
+            for (; i < Nd; i++) acc += tt[i];
+            if (tid < TC) sh.ub[tid] = acc; else sh.lb[tid - TC] = acc;
         }
         __syncthreads();
         return;
@@ -480,12 +492,18 @@ struct HeapStore {
     __device__ __forceinline__ HeapNode get(int i) const { return i < hl ? lds[i] : glb[i]; }
     __device__ __forceinline__ void set(int i, const HeapNode& v) const { if (i < hl) lds[i] = v; else glb[i] = v; }
 };
+__device__ __forceinline__ bool key_lower(float plb, float pw, float qlb, float qw) { return plb != qlb ? plb > qlb : pw < qw; }
+struct HeapKey { float lb, w; };
+__device__ __forceinline__ HeapKey heap_key(const HeapStore& a, int i) {
+    const HeapNode* p = i < a.hl ? a.lds + i : a.glb + i;
+    HeapKey k; k.lb = p->lb; k.w = p->w; return k;
+}
 __device__ __forceinline__ void heap_up(const HeapStore& a, int hole, const HeapNode& v) {
     int par = (hole - 1) / 2;
     while (hole > 0) {
-        const HeapNode pn = a.get(par);
-        if (!node_lower(pn, v)) break;
-        a.set(hole, pn); hole = par; par = (hole - 1) / 2;
+        const HeapKey pk = heap_key(a, par);                      // compare on (lb, w) only; move whole nodes only when needed
+        if (!key_lower(pk.lb, pk.w, v.lb, v.w)) break;
+        a.set(hole, a.get(par)); hole = par; par = (hole - 1) / 2;
     }
     a.set(hole, v);
 }
@@ -497,10 +515,9 @@ __device__ __forceinline__ void heap_pop(const HeapStore& a, int& n) {
         int hole = 0, child = 0;
         while (child < (len - 1) / 2) {
             child = 2 * (child + 1);
-            HeapNode c1 = a.get(child);
-            const HeapNode c0 = a.get(child - 1);
-            if (node_lower(c1, c0)) { child--; c1 = c0; }
-            a.set(hole, c1); hole = child;
+            const HeapKey k1 = heap_key(a, child), k0 = heap_key(a, child - 1);
+            if (key_lower(k1.lb, k1.w, k0.lb, k0.w)) child--;
+            a.set(hole, a.get(child)); hole = child;
         }
         if ((len & 1) == 0 && child == (len - 2) / 2) { child = 2 * (child + 1); a.set(hole, a.get(child - 1)); hole = child - 1; }
         heap_up(a, hole, v);
@@ -601,21 +618,30 @@ __global__ __launch_bounds__(BLOCK) void k_inner_bnb(DevTables T, const goicp_bn
         STAMP(3);
         if (T.use_fpfh) lattice_terms<BLOCK, PPT>(T, sh, 27, px, py, pz, fpbuf, false);
         STAMP(4);
+        if (penalties) {
+            // lanes 0-7 fold the corner terms of their child into sh.ub/sh.lb in parallel ...
+            if (tid < TC) {
+                const int j = tid;
+                float ub = sh.ub[j], lb = sh.lb[j];
+                // extremes over the cube's 8 corners (reference jly_goicp.cpp:431-549)
+                int minI = 0, maxI = 0; float minF = 0.f, maxF = 0.f;
+#pragma unroll
+                for (int c = 0; c < 8; c++) {
+                    const int l = ((j >> 2 & 1) + (c >> 2 & 1)) * 9 + ((j >> 1 & 1) + (c >> 1 & 1)) * 3 + ((j & 1) + (c & 1));
+                    if (T.use_compat) { int v = sh.cnt[l]; if (c == 0) { minI = maxI = v; } else { if (v > maxI) maxI = v; if (v < minI) minI = v; } }
+                    if (T.use_fpfh) { int v = (int)sh.fpv[l]; if (c == 0) { minF = maxF = (float)v; } else { if (v > maxF) maxF = (float)v; if (v < minF) minF = (float)v; } }
+                }
+                if (T.use_compat) { ub += T.reg * (float)(maxI * maxI); lb += T.reg * (float)(minI * minI); }
+                if (T.use_fpfh) { ub += T.regFPFH * (maxF * maxF); lb += T.regFPFH * (minF * minF); }
+                sh.ub[j] = ub; sh.lb[j] = lb;
+            }
+            __syncthreads();
+        }
         if (tid == 0) {
+            // ... and lane 0 replays the order-dependent part: incumbent update, prune, push (reference jly_goicp.cpp:554-575)
             cubes += 8;
             for (int j = 0; j < TC; j++) {
-                float ub = sh.ub[j], lb = sh.lb[j];
-                if (penalties) {
-                    // extremes over the cube's 8 corners (reference jly_goicp.cpp:431-549)
-                    int minI = 0, maxI = 0; float minF = 0.f, maxF = 0.f;
-                    for (int c = 0; c < 8; c++) {
-                        const int l = ((j >> 2 & 1) + (c >> 2 & 1)) * 9 + ((j >> 1 & 1) + (c >> 1 & 1)) * 3 + ((j & 1) + (c & 1));
-                        if (T.use_compat) { int v = sh.cnt[l]; if (c == 0) { minI = maxI = v; } else { if (v > maxI) maxI = v; if (v < minI) minI = v; } }
-                        if (T.use_fpfh) { int v = (int)sh.fpv[l]; if (c == 0) { minF = maxF = (float)v; } else { if (v > maxF) maxF = (float)v; if (v < minF) minF = (float)v; } }
-                    }
-                    if (T.use_compat) { ub += T.reg * (float)(maxI * maxI); lb += T.reg * (float)(minI * minI); }
-                    if (T.use_fpfh) { ub += T.regFPFH * (maxF * maxF); lb += T.regFPFH * (minF * minF); }
-                }
+                const float ub = sh.ub[j], lb = sh.lb[j];
                 if (ub < optErrorT) { optErrorT = ub; bx = sh.cube[j][0]; by = sh.cube[j][1]; bz = sh.cube[j][2]; bw = sh.cube[j][3]; found = 1; }
                 if (lb >= optErrorT) continue;                                  // reference jly_goicp.cpp:568
                 HeapNode nd; nd.x = sh.cube[j][0]; nd.y = sh.cube[j][1]; nd.z = sh.cube[j][2]; nd.w = sh.cube[j][3]; nd.ub = ub; nd.lb = lb;
@@ -853,7 +879,7 @@ static void pick_geometry(goicp_engine* h) {
     else if (Nd <= 4096) { h->block = 1024; h->ppt = 4; }
     else if (Nd <= 5120) { h->block = 1024; h->ppt = 5; }
     else { h->block = 512; h->ppt = 16; }
-    h->dyn_lds = (h->T.exact && !h->T.doTrim) ? (size_t)TC * Nd * sizeof(float) : 0;
+    h->dyn_lds = (h->T.exact && !h->T.doTrim) ? (size_t)2 * TC * Nd * sizeof(float) : 0;      // ub and lb addend rows
     // k_inner_bnb keeps the top of its queue in LDS behind the residual rows (24 B per node)
     h->rbuf_floats = (int)(h->dyn_lds / sizeof(float));
     h->heap_lds_nodes = 2048;
@@ -895,7 +921,7 @@ extern "C" int goicp_engine_create(const goicp_engine_desc* d, goicp_engine** ou
     T.use_compat = use_compat; T.use_fpfh = use_fpfh;
     { const char* e = getenv("GOICP_DBG"); T.dbg = e ? atoi(e) : 0; }
     { const char* e = getenv("GOICP_MAX_POPS"); if (e) h->max_pops = (unsigned)atoll(e); }
-    T.exact = (d->parity_mode && d->Nd <= 1536) ? 1 : 0;   // TC*Nd floats of LDS next to the static tile state
+    T.exact = (d->parity_mode && d->Nd <= 1024) ? 1 : 0;   // 2*TC*Nd floats of LDS next to the static tile state and the LDS heap
     const size_t ncell = (size_t)d->S * d->S * d->S;
     float* p_dist; CR(dev_upload(h, d->dt_dist, ncell, &p_dist)); T.dist = p_dist;
     float* p_dxyz; CR(dev_upload(h, d->data_xyz, (size_t)3 * d->Nd, &p_dxyz)); T.dxyz = p_dxyz;

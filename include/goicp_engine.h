@@ -76,7 +76,7 @@ typedef struct goicp_engine_desc {
     float   regularizationFPFH;
     int32_t device_id;
     /* 1: ub/lb summed in the reference's order (float, sequential over points; bit-exact for untrimmed
-     *    runs; used when Nd <= 1536, else falls back to 0).  0: fp64 tree reduction (order-free; within n*eps of the reference). */
+     *    runs; used when Nd <= 1024, else falls back to 0).  0: fp64 tree reduction (order-free; within n*eps of the reference). */
     int32_t parity_mode;
 } goicp_engine_desc;
 

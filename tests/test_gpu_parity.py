@@ -180,7 +180,7 @@ def test_synthetic_cloud_against_oracle(n, S, trim):
     e = goicp_amd.Engine(S=S, geom4=(o.geom[0], o.geom[2], o.geom[4], o.geom[6]), dist=dist, data_xyz=P["s"], weights=o.weights(),
                          maxrotdis=o.maxrotdis(), model_xyz=P["t"], inlier_num=o.inlier_num(), do_trim=trim >= 0.001, norm=2, parity_mode=1)
     rng = np.random.default_rng(n + S)
-    exact = trim < 0.001 and n <= 1536
+    exact = trim < 0.001 and n <= 1024
     for it in range(3):
         R = o.axis_angle(rng.uniform(-2, 2, 3).astype(np.float32))
         o.rotate(R); e.set_rotation(it, R)
