@@ -80,15 +80,31 @@ __device__ __forceinline__ unsigned dt_index(const DevTables& T, float X, float 
     if ((ax | ay | az) != 0) { const float a = (float)ax, b = (float)ay, c = (float)az; ext = sqrtf(a * a + b * b + c * c); }
     return (unsigned)((z * S + y) * S + x);
 }
-// one axis of dt_index(): clamped cell coordinate and signed out-of-grid offset
+// one axis of dt_index(): unclamped cell coordinate; clamping is a single v_med3_i32 and the out-of-grid offset is only
+// formed on the (rare) lanes that need it
+__device__ __forceinline__ int clamp_cell(int x, int S) {
+    int r;
+    asm("v_med3_i32 %0, %1, 0, %2" : "=v"(r) : "v"(x), "s"(S - 1));
+    return r;
+}
+__device__ __forceinline__ int grid_off(int x, int S) { return x < 0 ? x : (x >= S ? x - S + 1 : 0); }
 __device__ __forceinline__ int dt_axis(float v, double mn, double scale, int S, int& off) {
     const int x = cell_of(v, mn, scale);
-    off = x < 0 ? x : (x >= S ? x - S + 1 : 0);
+    off = grid_off(x, S);
     return min(max(x, 0), S - 1);
 }
 __device__ __forceinline__ float dt_ext(int ax, int ay, int az) {
     float ext = 0.f;
     if ((ax | ay | az) != 0) { const float a = (float)ax, b = (float)ay, c = (float)az; ext = sqrtf(a * a + b * b + c * c); }
+    return ext;
+}
+// extension length from UNCLAMPED cell coordinates (0 when the cell is inside the grid)
+__device__ __forceinline__ float dt_ext_raw(int x, int y, int z, int S) {
+    float ext = 0.f;
+    if (((unsigned)x >= (unsigned)S) | ((unsigned)y >= (unsigned)S) | ((unsigned)z >= (unsigned)S)) {
+        const float a = (float)grid_off(x, S), b = (float)grid_off(y, S), c = (float)grid_off(z, S);
+        ext = sqrtf(a * a + b * b + c * c);
+    }
     return ext;
 }
 __device__ __forceinline__ float dt_finish(const DevTables& T, float v, float ext) {
@@ -182,17 +198,29 @@ __device__ __forceinline__ void sweep_tile(const DevTables& T, TileShm<BLOCK>& s
         if (OCT) {
             // the 8 cubes are the 2x2x2 children of one node: child j sits at (j&1, j>>1&1, j>>2&1), so only two distinct
             // centre coordinates exist per axis and the (double) cell arithmetic is done 6 times instead of 24
-            int cx[2], cy[2], cz[2], ox[2], oy[2], oz[2];
+            int rx[2], ry[2], rz[2];
 #pragma unroll
             for (int q = 0; q < 2; q++) {
-                cx[q] = dt_axis(px[m] + sh.cen[q][0], T.xMin, T.scale, T.S, ox[q]);
-                cy[q] = dt_axis(py[m] + sh.cen[2 * q][1], T.yMin, T.scale, T.S, oy[q]);
-                cz[q] = dt_axis(pz[m] + sh.cen[4 * q][2], T.zMin, T.scale, T.S, oz[q]);
+                rx[q] = cell_of(px[m] + sh.cen[q][0], T.xMin, T.scale);
+                ry[q] = cell_of(py[m] + sh.cen[2 * q][1], T.yMin, T.scale);
+                rz[q] = cell_of(pz[m] + sh.cen[4 * q][2], T.zMin, T.scale);
             }
 #pragma unroll
             for (int j = 0; j < TC; j++) {
-                idx[j] = (unsigned)((cz[j >> 2 & 1] * T.S + cy[j >> 1 & 1]) * T.S + cx[j & 1]);
-                ext[j] = dt_ext(ox[j & 1], oy[j >> 1 & 1], oz[j >> 2 & 1]);
+                const int x = rx[j & 1], y = ry[j >> 1 & 1], z = rz[j >> 2 & 1];
+                idx[j] = (unsigned)((clamp_cell(z, T.S) * T.S + clamp_cell(y, T.S)) * T.S + clamp_cell(x, T.S));
+                ext[j] = dt_ext_raw(x, y, z, T.S);
+            }
+        } else if (sh.ctl[2]) {
+            // the 8 cubes form a row (same y and z centre, e.g. 8 x-neighbours of a level grid): the y and z cell
+            // arithmetic is shared, 10 axis computations instead of 24
+            const int y = cell_of(py[m] + sh.cen[0][1], T.yMin, T.scale), z = cell_of(pz[m] + sh.cen[0][2], T.zMin, T.scale);
+            const int rowbase = (clamp_cell(z, T.S) * T.S + clamp_cell(y, T.S)) * T.S;
+#pragma unroll
+            for (int j = 0; j < TC; j++) {
+                const int x = cell_of(px[m] + sh.cen[j][0], T.xMin, T.scale);
+                idx[j] = (unsigned)(rowbase + clamp_cell(x, T.S));
+                ext[j] = dt_ext_raw(x, y, z, T.S);
             }
         } else {
 #pragma unroll
@@ -353,22 +381,21 @@ __device__ __forceinline__ void sweep_tile(const DevTables& T, TileShm<BLOCK>& s
     const int wave = tid >> 6, lane = tid & 63;
 #pragma unroll
     for (int j = 0; j < TC; j++) {
-        double aub = 0.0, alb = 0.0;
+        // a lane's own PPT addends are summed in float (PPT <= 16 terms), everything across lanes in fp64
+        float fub = 0.f, flb = 0.f;
         const float mtd = sh.mtd[j];
         const unsigned thrj = thr[j];
 #pragma unroll
         for (int m = 0; m < PPT; m++) {
-            if (tid + m * BLOCK < Nd) {
-                const float d = r[j][m];
-                const bool in = !T.doTrim || __float_as_uint(d) < thrj;
-                if (in) {
-                    const float e = d - mtd;
-                    if (T.norm == 2) { aub += (double)(d * d); if (e > 0.f) alb += (double)(e * e); }
-                    else if (T.norm == 1) { aub += (double)d; if (e > 0.f) alb += (double)e; }
-                }
-            }
+            const float d = r[j][m];
+            const bool in = (tid + m * BLOCK < Nd) && (!T.doTrim || __float_as_uint(d) < thrj);
+            const float e = d - mtd;
+            const float tu = T.norm == 2 ? d * d : (T.norm == 1 ? d : 0.f);
+            const float tl = T.norm == 2 ? e * e : (T.norm == 1 ? e : 0.f);
+            fub += in ? tu : 0.f;
+            flb += (in && e > 0.f) ? tl : 0.f;
         }
-        const double u = wave_sum(aub), l = wave_sum(alb);
+        const double u = wave_sum((double)fub), l = wave_sum((double)flb);
         if (lane == 0) { sh.red[wave][2 * j] = u; sh.red[wave][2 * j + 1] = l; }
     }
     __syncthreads();
@@ -700,6 +727,11 @@ __global__ __launch_bounds__(BLOCK) void k_eval_cubes(DevTables T, const float4*
     }
     const bool penalties = T.use_compat || T.use_fpfh;
     __syncthreads();
+    if (tid == 0) {
+        bool row = true;
+        for (int j = 1; j < TC; j++) row = row && sh.cen[j][1] == sh.cen[0][1] && sh.cen[j][2] == sh.cen[0][2];
+        sh.ctl[2] = row ? 1 : 0;
+    }
     if (penalties && tid < 8 * TC) {
         const int j = tid >> 3, c = tid & 7;
         sh.lat[tid][0] = sh.cube[j][0] + (c & 1) * sh.cube[j][3];
