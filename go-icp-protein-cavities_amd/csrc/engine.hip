@@ -507,6 +507,77 @@ __device__ __forceinline__ void lattice_compat_oct(const DevTables& T, TileShm<B
     __syncthreads();
 }
 
+// c-FPFH means at the 27 points of the children's corner lattice (k_inner_bnb). Per data point: 9 axis computations,
+// the 27 nearest-occupied-cell ids fetched together, the point's own descriptor row held in registers, and a lattice
+// point that resolves to the same occupied cell as its predecessor reuses the predecessor's minimum (frequent at deep
+// levels, where the lattice spacing is below the cell size). The per-lattice-point mean is then summed sequentially in
+// float (the reference truncates it to int, so it must round the same way) from rows kept in LDS when they fit.
+template <int BLOCK, int PPT>
+__device__ __forceinline__ void lattice_fpfh_oct(const DevTables& T, TileShm<BLOCK>& sh, const float (&px)[PPT], const float (&py)[PPT], const float (&pz)[PPT],
+                                                 float* rows /* [27*Nd], LDS or global */) {
+    const int tid = threadIdx.x;
+    const int Nd = T.Nd, S = T.S;
+#pragma unroll
+    for (int m = 0; m < PPT; m++) {
+        const int i = min(tid + m * BLOCK, Nd - 1);
+        const bool valid = tid + m * BLOCK < Nd;
+        int cx[3], cy[3], cz[3];
+#pragma unroll
+        for (int a = 0; a < 3; a++) {
+            cx[a] = min(max(cell_of(px[m] + sh.lat[a][0], T.xMin, T.scale), 0), S - 1);
+            cy[a] = min(max(cell_of(py[m] + sh.lat[3 * a][1], T.yMin, T.scale), 0), S - 1);
+            cz[a] = min(max(cell_of(pz[m] + sh.lat[9 * a][2], T.zMin, T.scale), 0), S - 1);
+        }
+        int o[27];
+#pragma unroll
+        for (int l = 0; l < 27; l++) o[l] = T.occ[(size_t)((cz[l / 9] * S + cy[(l / 3) % 3]) * S + cx[l % 3])];
+        float f[GOICP_FPFH_BINS];
+        const float* frow = T.dfpfh + (size_t)GOICP_FPFH_BINS * i;
+#pragma unroll
+        for (int b = 0; b < GOICP_FPFH_BINS; b++) f[b] = frow[b];
+        int prev_o = -2; float prev_min = 0.f;
+#pragma unroll
+        for (int l = 0; l < 27; l++) {
+            const int ol = o[l];
+            float minD;
+            if (ol == prev_o) minD = prev_min;
+            else {
+                minD = 1000000000.f;
+                if (ol >= 0) {
+                    for (int p = T.occ_ptr[ol]; p < T.occ_ptr[ol + 1]; p++) {
+                        const float* g = T.mfpfh + (size_t)GOICP_FPFH_BINS * T.occ_pts[p];
+                        float gg[GOICP_FPFH_BINS];
+#pragma unroll
+                        for (int b = 0; b < GOICP_FPFH_BINS; b++) gg[b] = g[b];
+                        float diff = 0.f;
+#pragma unroll
+                        for (int b = 0; b < GOICP_FPFH_BINS; b++) if (b >= T.b0 && b < T.b1) diff += fabsf(f[b] - gg[b]);
+                        if (diff < minD) minD = diff;
+                    }
+                }
+                prev_o = ol; prev_min = minD;
+            }
+            if (valid) rows[(size_t)l * Nd + i] = minD;
+        }
+    }
+    __syncthreads();
+    if (tid < 27) {
+        const float* fr = rows + (size_t)tid * Nd;
+        float acc = 0.f;
+        int i = 0;
+        for (; i + 16 <= Nd; i += 16) {
+            float v[16];
+#pragma unroll
+            for (int q = 0; q < 16; q++) v[q] = fr[i + q];
+#pragma unroll
+            for (int q = 0; q < 16; q++) acc += v[q];
+        }
+        for (; i < Nd; i++) acc += fr[i];
+        sh.fpv[tid] = acc / (float)Nd;
+    }
+    __syncthreads();
+}
+
 // ---------------------------------------------------------------------------------------------
 // binary heap with the element order of std::priority_queue<TRANSNODE> (reference jly_goicp.h:75-87):
 // the hole is sifted to a leaf along the not-lower child, then the displaced value is sifted up.
@@ -557,7 +628,7 @@ __device__ __forceinline__ void heap_pop(const HeapStore& a, int& n) {
 // ---------------------------------------------------------------------------------------------
 template <int BLOCK, int PPT>
 __global__ __launch_bounds__(BLOCK) void k_inner_bnb(DevTables T, const goicp_bnb_job* __restrict__ jobs, goicp_bnb_result* __restrict__ results,
-                                                      HeapNode* heaps, int heap_cap, float* fpscratch, unsigned max_pops, int heap_lds_nodes, int rbuf_floats) {
+                                                      HeapNode* heaps, int heap_cap, float* fpscratch, unsigned max_pops, int heap_lds_nodes, int rbuf_floats, int fp_lds) {
     __shared__ TileShm<BLOCK> sh;
     __shared__ HeapNode parent;
     extern __shared__ float rbuf[];              // [rbuf_floats] parity-mode residual rows, then the LDS part of the heap
@@ -567,6 +638,7 @@ __global__ __launch_bounds__(BLOCK) void k_inner_bnb(DevTables T, const goicp_bn
     HeapStore heap;
     heap.glb = heaps + (size_t)blockIdx.x * heap_cap; heap.lds = reinterpret_cast<HeapNode*>(rbuf + rbuf_floats); heap.hl = heap_lds_nodes;
     float* fpbuf = fpscratch ? fpscratch + (size_t)blockIdx.x * NLMAX * Nd : nullptr;
+    if (fp_lds) fpbuf = rbuf + rbuf_floats + (size_t)heap_lds_nodes * (sizeof(HeapNode) / sizeof(float));     // c-FPFH rows behind the LDS heap
 
     // K5 fused: pDataTemp = R*p, float, left to right (reference jly_goicp.cpp:750-756)
     float px[PPT], py[PPT], pz[PPT], pw[PPT], prho[PPT];
@@ -643,7 +715,7 @@ __global__ __launch_bounds__(BLOCK) void k_inner_bnb(DevTables T, const goicp_bn
         STAMP(2);
         if (T.use_compat) lattice_compat_oct<BLOCK, PPT>(T, sh, px, py, pz);
         STAMP(3);
-        if (T.use_fpfh) lattice_terms<BLOCK, PPT>(T, sh, 27, px, py, pz, fpbuf, false);
+        if (T.use_fpfh) lattice_fpfh_oct<BLOCK, PPT>(T, sh, px, py, pz, fpbuf);
         STAMP(4);
         if (penalties) {
             // lanes 0-7 fold the corner terms of their child into sh.ub/sh.lb in parallel ...
@@ -851,7 +923,7 @@ struct goicp_engine {
     float* d_fpscratch; size_t fp_blocks;
     float* d_cubes; float* d_ub; float* d_lb; int cube_cap; int2* d_groups; std::vector<int2> groups_host;
     double* d_Rt; float* d_Rtf; float* d_dist; int* d_int; float* d_lat; int lat_cap; int* d_cnt; float* d_fp;
-    int block, ppt; size_t dyn_lds; size_t dyn_lds_bnb; int heap_lds_nodes; int rbuf_floats;
+    int block, ppt; size_t dyn_lds; size_t dyn_lds_bnb; int heap_lds_nodes; int rbuf_floats; int fp_lds;
     unsigned max_pops;
     uint64_t n_cubes, n_lookups; double kernel_ms;
     std::string err;
@@ -916,6 +988,8 @@ static void pick_geometry(goicp_engine* h) {
     h->rbuf_floats = (int)(h->dyn_lds / sizeof(float));
     h->heap_lds_nodes = 2048;
     h->dyn_lds_bnb = h->dyn_lds + (size_t)h->heap_lds_nodes * sizeof(HeapNode);
+    h->fp_lds = 0;
+    if (h->T.use_fpfh && h->dyn_lds_bnb + (size_t)27 * Nd * sizeof(float) + sizeof(TileShm<1024>) + 1024 <= 160 * 1024) { h->fp_lds = 1; h->dyn_lds_bnb += (size_t)27 * Nd * sizeof(float); }
 }
 
 extern "C" int goicp_engine_create(const goicp_engine_desc* d, goicp_engine** out) {
@@ -1181,7 +1255,7 @@ static int run_bnb(goicp_engine* h, const goicp_bnb_job* jobs, int njobs, goicp_
     if (rc != GOICP_OK) return rc;
     HIPCHK(h, hipMemcpyAsync(h->d_jobs, jobs, (size_t)njobs * sizeof(goicp_bnb_job), hipMemcpyHostToDevice, h->stream));
     HIPCHK(h, hipEventRecord(h->ev0, h->stream));
-#define CALL(B, P) hipLaunchKernelGGL((k_inner_bnb<B, P>), dim3(njobs), dim3(B), h->dyn_lds_bnb, h->stream, h->T, h->d_jobs, h->d_results, heaps, cap, h->d_fpscratch, h->max_pops, h->heap_lds_nodes, h->rbuf_floats)
+#define CALL(B, P) hipLaunchKernelGGL((k_inner_bnb<B, P>), dim3(njobs), dim3(B), h->dyn_lds_bnb, h->stream, h->T, h->d_jobs, h->d_results, heaps, cap, h->d_fpscratch, h->max_pops, h->heap_lds_nodes, h->rbuf_floats, h->fp_lds)
     DISPATCH_GEOM(h, CALL);
 #undef CALL
     HIPCHK(h, hipGetLastError());

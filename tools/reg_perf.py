@@ -22,7 +22,8 @@ def run(name, P, cfgd, spec=8):
 
 G = load_register()
 P1 = load_clouds("pair1"); P2 = load_clouds("pair2")
-run("pair1_default", P1, G["pair1_default"]["cfg"])
+for _ in range(3):
+    run("pair1_default", P1, G["pair1_default"]["cfg"])
 run("pair2_default", P2, G["pair2_default"]["cfg"])
 run("pair2_spec1", P2, G["pair2_default"]["cfg"], spec=1)
 run("pair2_spec16", P2, G["pair2_default"]["cfg"], spec=16)
