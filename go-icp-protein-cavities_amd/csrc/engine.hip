@@ -32,6 +32,7 @@
 #include "goicp_engine.h"
 
 #define TC 8            // cubes per workgroup tile (the 8 children of one queue pop)
+#define CAND_CAP 128     // threshold-bin members refined inside one wave; larger bins take the generic byte passes
 #define NLMAX 64        // lattice points per tile: 27 (shared child corners) or 8*TC (free cubes)
 #define SQRT3_D 1.732050808   // jly_goicp.h:45
 
@@ -172,6 +173,9 @@ struct TileShm {
     int rem[TC];
     unsigned maxb[TC];        // bit pattern of the largest residual per cube
     int fallback;
+    int zc[TC];               // residuals that are exactly 0 (clamped), counted with ballots instead of LDS adds
+    int ncand[TC];            // members of the threshold bin collected for the in-wave refinement
+    unsigned cand[TC][CAND_CAP];
     double red[BLOCK / 64][2 * TC];
     float ub[TC], lb[TC];
     float lat[NLMAX][3];
@@ -285,7 +289,7 @@ __device__ __forceinline__ void sweep_tile(const DevTables& T, TileShm<BLOCK>& s
     if (T.doTrim && !(T.dbg & 1)) {
         const int wv = tid >> 6, ln = tid & 63;
         for (int k = tid; k < TC * 1024; k += BLOCK) (&sh.hist[0][0])[k] = 0u;
-        if (tid < TC) { sh.prefix[tid] = 0u; sh.rem[tid] = T.inlierNum - 1; sh.maxb[tid] = 0u; }
+        if (tid < TC) { sh.prefix[tid] = 0u; sh.rem[tid] = T.inlierNum - 1; sh.maxb[tid] = 0u; sh.zc[tid] = 0; sh.ncand[tid] = 0; }
         if (tid == 0) sh.fallback = 0;
         __syncthreads();
         // (1) largest residual per cube: fixes the 8-octave window of the first pass
@@ -301,16 +305,21 @@ __device__ __forceinline__ void sweep_tile(const DevTables& T, TileShm<BLOCK>& s
         __syncthreads();
         // (2) first pass: 10-bit digit = top 16 bits (sign, exponent, 7 mantissa bits) relative to the cube's maximum:
         //     1024 monotone bins over the 8 octaves below the maximum, so the values spread over hundreds of LDS words
-        //     instead of piling onto the 2-3 exponent bytes a plain byte pass would see
+        //     instead of piling onto the 2-3 exponent bytes a plain byte pass would see. Residuals clamped to exactly 0
+        //     (frequent once a rotation-uncertainty radius is subtracted) are bit-identical and would serialise on one
+        //     LDS word, so they are counted with ballots and kept out of the histogram.
 #pragma unroll
-        for (int m = 0; m < PPT; m++) {
-            const bool valid = tid + m * BLOCK < Nd;
+        for (int j = 0; j < TC; j++) {
+            const int base16 = max(0, (int)(sh.maxb[j] >> 16) - 1023);
+            int z = 0;
 #pragma unroll
-            for (int j = 0; j < TC; j++) {
-                const int base16 = max(0, (int)(sh.maxb[j] >> 16) - 1023);
-                const int key = max(0, (int)(__float_as_uint(r[j][m]) >> 16) - base16);
-                hist_add(sh.hist[j], (unsigned)key, valid, ln);
+            for (int m = 0; m < PPT; m++) {
+                const bool valid = tid + m * BLOCK < Nd;
+                const unsigned bits = __float_as_uint(r[j][m]);
+                z += __popcll(__ballot(valid && bits == 0u));
+                if (valid && bits != 0u) atomicAdd(&sh.hist[j][max(0, (int)(bits >> 16) - base16)], 1u);
             }
+            if (ln == 0 && z) atomicAdd(&sh.zc[j], z);
         }
         __syncthreads();
         for (int j = wv; j < TC; j += BLOCK / 64) {     // one wave scans the 1024 bins of a cube: 16 per lane
@@ -320,7 +329,13 @@ __device__ __forceinline__ void sweep_tile(const DevTables& T, TileShm<BLOCK>& s
             int incl = mine;
 #pragma unroll
             for (int off = 1; off < 64; off <<= 1) { const int t = __shfl_up(incl, off, 64); if (ln >= off) incl += t; }
-            const int rem = sh.rem[j];
+            const int zc = sh.zc[j];
+            const int rank = sh.rem[j];
+            if (rank < zc) {                                  // the threshold is one of the zeros
+                if (ln == 0) { sh.prefix[j] = 0u; sh.rem[j] = rank; sh.ncand[j] = -1; }
+                continue;
+            }
+            const int rem = rank - zc;
             const unsigned long long over = __ballot(incl > rem);
             const int owner = over ? __ffsll((long long)over) - 1 : 63;
             if (ln == owner) {
@@ -328,18 +343,56 @@ __device__ __forceinline__ void sweep_tile(const DevTables& T, TileShm<BLOCK>& s
                 int b = 0;
 #pragma unroll
                 for (int q = 0; q < 15; q++) { if (b == q && rr >= (int)c[q]) { rr -= (int)c[q]; b = q + 1; } }
+                unsigned cb = c[0];
+#pragma unroll
+                for (int q = 1; q < 16; q++) if (b == q) cb = c[q];
                 const int bin = 16 * ln + b;
                 const int base16 = max(0, (int)(sh.maxb[j] >> 16) - 1023);
-                if (bin == 0 && base16 > 0) sh.fallback = 1;      // threshold below the window: generic passes decide
+                // threshold below the window, or a crowded bin: the generic byte passes decide
+                if ((bin == 0 && base16 > 0) || cb > CAND_CAP) sh.fallback = 1;
                 sh.prefix[j] = (unsigned)(base16 + bin) << 16;
-                sh.rem[j] = rr;
+                sh.rem[j] = rr;                               // rank among the members of the threshold bin
             }
         }
         __syncthreads();
+        if (!sh.fallback) {
+            // (3) collect the members of each threshold bin (a handful) and finish the low 16 bits inside one wave
+#pragma unroll
+            for (int j = 0; j < TC; j++) {
+                const unsigned p16 = sh.prefix[j] >> 16;
+                if (sh.ncand[j] < 0) continue;                // threshold already known (zero)
+#pragma unroll
+                for (int m = 0; m < PPT; m++) {
+                    const unsigned bits = __float_as_uint(r[j][m]);
+                    if (tid + m * BLOCK < Nd && bits != 0u && (bits >> 16) == p16) {
+                        const int pos = atomicAdd(&sh.ncand[j], 1);
+                        if (pos < CAND_CAP) sh.cand[j][pos] = bits;
+                    }
+                }
+            }
+            __syncthreads();
+            for (int j = wv; j < TC; j += BLOCK / 64) {
+                const int nc = sh.ncand[j];
+                if (nc < 0) continue;
+                const bool v0 = ln < nc, v1 = ln + 64 < nc;
+                const unsigned c0 = v0 ? sh.cand[j][ln] : 0u, c1 = v1 ? sh.cand[j][ln + 64] : 0u;
+                const int rem = sh.rem[j];
+                unsigned pre = sh.prefix[j];
+#pragma unroll
+                for (int b = 15; b >= 0; b--) {
+                    const unsigned cnd = pre | (1u << b);
+                    const int cnt = __popcll(__ballot(v0 && c0 < cnd)) + __popcll(__ballot(v1 && c1 < cnd));
+                    if (cnt <= rem) pre = cnd;                // the rem-th member is >= cnd
+                }
+                const int less = __popcll(__ballot(v0 && c0 < pre)) + __popcll(__ballot(v1 && c1 < pre));
+                if (ln == 0) { sh.prefix[j] = pre; sh.rem[j] = rem - less; }
+            }
+            __syncthreads();
+        }
         const bool generic = sh.fallback != 0;
         if (generic) { if (tid < TC) { sh.prefix[tid] = 0u; sh.rem[tid] = T.inlierNum - 1; } }
-        // (3) remaining bytes, MSB first (all four when the window missed)
-        for (int pass = generic ? 3 : 1; pass >= 0; pass--) {
+        // (4) generic path: four byte passes, MSB first, when the window missed or a bin was crowded
+        for (int pass = generic ? 3 : -1; pass >= 0; pass--) {
             __syncthreads();
             for (int k = tid; k < TC * 256; k += BLOCK) sh.hist[k >> 8][k & 255] = 0u;
             __syncthreads();

@@ -128,6 +128,7 @@ public:
 
 private:
     goicp_engine* eng_ = nullptr;
+    double icp_ms_ = 0;
     std::vector<float> normData_, minDis_;
     std::vector<int32_t> icp_id_data_, icp_id_model_, opt_id_data_, opt_id_model_;
     float OuterBnB();                      // reference jly_goicp.cpp:582-876

@@ -10,6 +10,7 @@
 #include <cstring>
 #include <iostream>
 #include <array>
+#include <chrono>
 #include <limits>
 #include <map>
 #include <vector>
@@ -388,6 +389,8 @@ float GoICP::icp_run(Matrix& R, Matrix& t) {
 // reference jly_goicp.cpp:102-178: DT lookups on the device, sums in the reference's order on the host
 float GoICP::ICP(Matrix& R_icp, Matrix& t_icp) {
     if (!eng_) return std::numeric_limits<float>::quiet_NaN();
+    const double t_icp0 = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count();
+    struct Acc { double* a; double t0; ~Acc() { *a += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count() - t0; } } acc_{&icp_ms_, t_icp0};
     icp_run(R_icp, t_icp);
     if (status != GOICP_OK) return std::numeric_limits<float>::quiet_NaN();
     double R[9], t[3];
@@ -624,11 +627,18 @@ float GoICP::OuterBnB() {
     return optError;
 }
 
+static double now_ms() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+
 float GoICP::Register() {
-    trace.clear(); stats = RegisterStats(); job_log.clear(); result_log.clear();
+    trace.clear(); stats = RegisterStats(); job_log.clear(); result_log.clear(); icp_ms_ = 0;
+    const bool timing = getenv("GOICP_TIMING") != nullptr;
+    const double t0 = now_ms();
     Initialize();
+    const double t1 = now_ms();
     if (!eng_) return std::numeric_limits<float>::quiet_NaN();
     OuterBnB();
+    const double t2 = now_ms();
+    if (timing) fprintf(stderr, "[goicp timing] Initialize+engine %.1f ms, OuterBnB %.1f ms (ICP host+device %.1f ms)\n", t1 - t0, t2 - t1, icp_ms_);
     double ms = 0; uint64_t ce = 0, lk = 0;
     goicp_engine_stats(eng_, &ce, &lk, &ms);
     stats.engine_kernel_ms = ms;
