@@ -58,6 +58,7 @@ def main():
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--no-register", action="store_true", help="skip the end-to-end registration leg")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
+    ap.add_argument("--cavity-pairs", type=int, default=8, help="cavity-like pairs registered per rank")
     args = ap.parse_args()
 
     import torch
@@ -158,10 +159,46 @@ def main():
                    inner_launches=out["stats"]["inner_launches"], engine_kernel_ms=out["kernel_ms"],
                    dR_vs_planted=float(np.abs(out["R"] - P["Rtrue"]).max()), dt_vs_planted=float(np.abs(out["t"] - P["ttrue"]).max()))
 
+    # ---- cavity-pair registrations/s: BASELINE configs[3] shape (cavity-sized clouds, default config + c-FPFH), sharded ----
+    cav = None
+    if not args.no_register:
+        n_pairs = args.cavity_pairs
+        cfg4 = goicp_amd.cfg_vector(cfpfh=1, regularizationFPFH=0.000005)      # shipped defaults otherwise (20^3 DT, compat penalty, ponderation)
+        rngc = np.random.default_rng(20260103)
+        sizes = rngc.integers(150, 401, size=n_pairs * world)
+        mine = list(range(rank, n_pairs * world, world))                       # static round-robin shard, no data-path collective
+        pairs = [synth_pair(int(sizes[k]), seed=777000 + k, noise=0.01, outlier_frac=0.05, theta_range=(0.3, np.pi), corr_features=True) for k in mine]
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        errs = []; cev = 0
+        for Pc in pairs:
+            gc = goicp_amd.GoICP(cfg4, device_id=local)
+            gc.set_clouds(Pc["t"], Pc["s"], Pc["tc"], Pc["sc"], Pc["tf"], Pc["sf"])
+            gc.build_dt()
+            oc = gc.register()
+            errs.append(float(oc["error"])); cev += oc["stats"]["cube_evals"]
+            gc.close()
+        t_cav = time.perf_counter() - t0
+        rec = torch.tensor([t_cav, float(cev)], dtype=torch.float64, device=dev)
+        if world > 1:
+            tmax = rec.clone(); dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+            tsum = rec.clone(); dist.all_reduce(tsum, op=dist.ReduceOp.SUM)
+            t_cav = float(tmax[0].item()); cev = int(tsum[1].item())
+            # the one exchange of the batch driver: all_gather of the per-pair results (RCCL)
+            loc = torch.tensor(errs, dtype=torch.float64, device=dev)
+            outs = [torch.empty_like(loc) for _ in range(world)]
+            dist.all_gather(outs, loc)
+        cav = dict(pairs=n_pairs * world, seconds=t_cav, cavity_pair_registrations_per_sec=n_pairs * world / t_cav, cube_evals=cev,
+                   config="default config.txt + cfpfh=1, regularizationFPFH=5e-6; synthetic cavity-like pairs, N in [150,400]")
+
     # ---- CPU baseline: the unmodified reference (oracle/_ref) replaying the same InnerBnB calls, bounded -------
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu:
         cpu = cpu_baseline(g, P, cfg, args, reg)
+        if cpu is not None and cav is not None:
+            cpu.update(cpu_cavity_baseline(pairs, cfg4, cav))
 
     # the DT / engine can go now
     g.close()
@@ -186,6 +223,7 @@ def main():
                          "point_lookups_per_sec": value / world * nd},
             "cpu_baseline": cpu,
             "registration": reg,
+            "cavity_batch": cav,
         }
         print(json.dumps(line))
     if world > 1:
@@ -231,6 +269,21 @@ def cpu_baseline(g, P, cfg, args, reg):
             "sample": "first %d InnerBnB calls of this registration replayed by the reference's GoICP::InnerBnB (%d cube-evals, %.1f s, "
                       "%d result mismatches > 1e-5)" % (ncalls, evals_counted, spent, mismatches),
             "host_cpus": os.cpu_count()}
+
+
+def cpu_cavity_baseline(pairs, cfg4, cav):
+    """The reference's whole Register() (BuildDT included) on the same cavity-like pairs, one host core."""
+    from oracle import refbind
+    if not os.path.exists(refbind.REF_SO):
+        return {}
+    t0 = time.perf_counter(); n = 0; mism = 0
+    for Pc in pairs:
+        r = refbind.Ref(); r.set_config(cfg4); r.set_clouds(Pc["t"], Pc["s"], Pc["tc"], Pc["sc"], Pc["tf"], Pc["sf"])
+        r.build_dt(); r.register(); n += 1
+        if time.perf_counter() - t0 > 40.0:
+            break
+    dt = time.perf_counter() - t0
+    return {"cavity_pair_registrations_per_sec": n / dt, "cavity_sample": "%d of the %d cavity-like pairs of rank 0, reference BuildDT()+Register(), %.1f s" % (n, len(pairs), dt)}
 
 
 if __name__ == "__main__":

@@ -46,6 +46,8 @@ struct DevTables {
     const int* occ_pts;      // model ids
     const float* mfpfh;      // [Nm*41]
     const float* dfpfh;      // [Nd*41]
+    const float* fpE;        // [Nd*nOcc] min over the model points of occupied cell o of the L1 distance to data point i's descriptor
+    int nOcc;
     const float* dxyz;       // [Nd*3]
     const uint8_t* dcls;     // [Nd] colour class of each data point
     const float* weights;    // [Nd]
@@ -129,19 +131,27 @@ __device__ __forceinline__ size_t clamped_cell(const DevTables& T, float X, floa
 }
 
 // min over the model points of the nearest occupied cell of the L1 distance between c-FPFH rows
-// (computeFPFHDifference(false,...), reference jly_goicp.cpp:1642-1681)
+// (computeFPFHDifference(false,...), reference jly_goicp.cpp:1642-1681). The value depends only on (data point,
+// occupied cell), not on the pose, so it is tabulated once per engine (k_fpfh_table) and the hot path does one gather.
 __device__ __forceinline__ float fpfh_min(const DevTables& T, int i, float X, float Y, float Z) {
-    int o = T.occ[clamped_cell(T, X, Y, Z)];
-    float minD = 1000000000.f;
-    if (o < 0) return minD;
+    const int o = T.occ[clamped_cell(T, X, Y, Z)];
+    return o < 0 ? 1000000000.f : T.fpE[(size_t)i * T.nOcc + o];
+}
+
+// E[i][o] = min_p sum_b |f_i[b] - g_p[b]| over the model points p of occupied cell o, bins b0..b1-1 added in order (float)
+__global__ void k_fpfh_table(DevTables T, float* __restrict__ E) {
+    const size_t k = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= (size_t)T.Nd * T.nOcc) return;
+    const int i = (int)(k / T.nOcc), o = (int)(k % T.nOcc);
     const float* f = T.dfpfh + (size_t)GOICP_FPFH_BINS * i;
+    float minD = 1000000000.f;
     for (int p = T.occ_ptr[o]; p < T.occ_ptr[o + 1]; p++) {
         const float* g = T.mfpfh + (size_t)GOICP_FPFH_BINS * T.occ_pts[p];
         float diff = 0.f;
         for (int b = T.b0; b < T.b1; b++) diff += fabsf(f[b] - g[b]);
         if (diff < minD) minD = diff;
     }
-    return minD;
+    E[k] = minD;
 }
 
 __device__ __forceinline__ double wave_sum(double v) {
@@ -584,34 +594,12 @@ __device__ __forceinline__ void lattice_fpfh_oct(const DevTables& T, TileShm<BLO
         int o[27];
 #pragma unroll
         for (int l = 0; l < 27; l++) o[l] = T.occ[(size_t)((cz[l / 9] * S + cy[(l / 3) % 3]) * S + cx[l % 3])];
-        float f[GOICP_FPFH_BINS];
-        const float* frow = T.dfpfh + (size_t)GOICP_FPFH_BINS * i;
+        float v[27];
+        const float* Erow = T.fpE + (size_t)i * T.nOcc;
 #pragma unroll
-        for (int b = 0; b < GOICP_FPFH_BINS; b++) f[b] = frow[b];
-        int prev_o = -2; float prev_min = 0.f;
+        for (int l = 0; l < 27; l++) v[l] = Erow[max(o[l], 0)];            // 27 gathers in flight
 #pragma unroll
-        for (int l = 0; l < 27; l++) {
-            const int ol = o[l];
-            float minD;
-            if (ol == prev_o) minD = prev_min;
-            else {
-                minD = 1000000000.f;
-                if (ol >= 0) {
-                    for (int p = T.occ_ptr[ol]; p < T.occ_ptr[ol + 1]; p++) {
-                        const float* g = T.mfpfh + (size_t)GOICP_FPFH_BINS * T.occ_pts[p];
-                        float gg[GOICP_FPFH_BINS];
-#pragma unroll
-                        for (int b = 0; b < GOICP_FPFH_BINS; b++) gg[b] = g[b];
-                        float diff = 0.f;
-#pragma unroll
-                        for (int b = 0; b < GOICP_FPFH_BINS; b++) if (b >= T.b0 && b < T.b1) diff += fabsf(f[b] - gg[b]);
-                        if (diff < minD) minD = diff;
-                    }
-                }
-                prev_o = ol; prev_min = minD;
-            }
-            if (valid) rows[(size_t)l * Nd + i] = minD;
-        }
+        for (int l = 0; l < 27; l++) if (valid) rows[(size_t)l * Nd + i] = o[l] < 0 ? 1000000000.f : v[l];
     }
     __syncthreads();
     if (tid < 27) {
@@ -1127,6 +1115,16 @@ extern "C" int goicp_engine_create(const goicp_engine_desc* d, goicp_engine** ou
             int* p_oi; CR(dev_upload(h, occ_pts.data(), occ_pts.size(), &p_oi)); T.occ_pts = p_oi;
             float* p_mf; CR(dev_upload(h, d->model_fpfh, (size_t)GOICP_FPFH_BINS * d->Nm, &p_mf)); T.mfpfh = p_mf;
             float* p_df; CR(dev_upload(h, d->data_fpfh, (size_t)GOICP_FPFH_BINS * d->Nd, &p_df)); T.dfpfh = p_df;
+            // pose-independent table of descriptor distances (data point x occupied cell), built once on the device
+            T.nOcc = (int)occ_ptr.size() - 1;
+            const size_t ne = (size_t)d->Nd * (size_t)std::max(T.nOcc, 1);
+            float* p_E; CR(dev_upload<float>(h, nullptr, ne, &p_E));
+            if (T.nOcc > 0) {
+                hipLaunchKernelGGL(k_fpfh_table, dim3((unsigned)((ne + 255) / 256)), dim3(256), 0, h->stream, T, p_E);
+                CRH(hipGetLastError());
+                CRH(hipStreamSynchronize(h->stream));
+            }
+            T.fpE = p_E;
         }
     }
     if (cls.size() > 16) { h->err = "more than 16 distinct colour codes"; CR(GOICP_ERR_ARG); }

@@ -42,7 +42,7 @@ def oracle_for(P, cfgvec, H=None, nd=None):
     return o
 
 
-def synth_pair(n, seed=20260101, noise=0.01, outlier_frac=0.10, tmax=0.2, theta_range=(0.3, np.pi)):
+def synth_pair(n, seed=20260101, noise=0.01, outlier_frac=0.10, tmax=0.2, theta_range=(0.3, np.pi), corr_features=False):
     """SURVEY.md 8(d) synthetic generator: shell cloud on 6 overlapping spheres, centred, max-norm 1,
     6 significant digits; data = permuted, rotated, translated, noised copy with outliers."""
     rng = np.random.default_rng(seed)
@@ -58,12 +58,14 @@ def synth_pair(n, seed=20260101, noise=0.01, outlier_frac=0.10, tmax=0.2, theta_
     K = np.array([[0, -k[2], k[1]], [k[2], 0, -k[0]], [-k[1], k[0], 0]])
     Rt = np.eye(3) + np.sin(th) * K + (1 - np.cos(th)) * K @ K
     tt = rng2.uniform(-tmax, tmax, 3)
-    d = m[rng2.permutation(n)]
+    perm = rng2.permutation(n)
+    d = m[perm]
     # data such that  Rt*d + tt ~= model  <=> d = Rt^T (m - tt)
     d = (d - tt) @ Rt + rng2.normal(scale=noise, size=(n, 3))
     nout = int(outlier_frac * n)
+    out_idx = rng2.choice(n, nout, replace=False) if nout else np.zeros(0, int)
     if nout:
-        d[rng2.choice(n, nout, replace=False)] = rng2.uniform(-1, 1, (nout, 3))
+        d[out_idx] = rng2.uniform(-1, 1, (nout, 3))
     d = np.array([[float("%g" % x) for x in row] for row in d])
     props = np.array([8204959, 30894, 15219528, 15231913, 4646984, 16741671, 7566712, 0], np.int32)
     mc = props[rng.integers(0, 8, n)]; dc = props[rng2.integers(0, 8, n)]
@@ -72,4 +74,10 @@ def synth_pair(n, seed=20260101, noise=0.01, outlier_frac=0.10, tmax=0.2, theta_
         a = r.uniform(0, 1, (k, 33)); a = a / a.sum(1, keepdims=True) * 600
         b = r.uniform(0, 1, (k, 8)); b = b / b.sum(1, keepdims=True) * 200
         return np.concatenate([a, b], 1).astype(np.float32)
-    return dict(t=m.astype(np.float32), s=d.astype(np.float32), tc=mc, sc=dc, tf=fp(rng, n), sf=fp(rng2, n), Rtrue=Rt, ttrue=tt)
+    mf = fp(rng, n); df = fp(rng2, n)
+    if corr_features:
+        # corresponding points carry the model point's colour and (slightly perturbed) descriptor, as real cavity pairs do
+        inl = np.ones(n, bool); inl[out_idx] = False
+        dc = np.where(inl, mc[perm], dc)
+        df = np.where(inl[:, None], (mf[perm] * (1 + rng2.normal(scale=0.02, size=(n, 41)))).astype(np.float32), df)
+    return dict(t=m.astype(np.float32), s=d.astype(np.float32), tc=mc, sc=dc, tf=mf, sf=df, Rtrue=Rt, ttrue=tt)

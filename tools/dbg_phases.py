@@ -6,7 +6,7 @@ import goicp_amd
 from oracle.refbind import cfg_vector
 from helpers import load_clouds, load_hotpath
 from test_gpu_parity import engine_from_hotpath
-for name, pn in (("pair2_S50","pair2"),("pair1_default","pair1"),("pair1_trim","pair1")):
+for name, pn in (("pair1_fpfh","pair1"),("pair1_default","pair1"),("pair1_trim","pair1")):
     H = load_hotpath(name); P = load_clouds(pn)
     e = engine_from_hotpath(H, P)
     cfg = H["cfg"]; init = tuple(np.float32(cfg[5:9]))
