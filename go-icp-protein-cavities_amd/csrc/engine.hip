@@ -892,6 +892,21 @@ __global__ __launch_bounds__(BLOCK) void k_corner_terms(DevTables T, const float
     for (int l = tid; l < nl; l += BLOCK) { cnt_out[base + l] = T.use_compat ? sh.cnt[l] : 0; fp_out[base + l] = T.use_fpfh ? sh.fpv[l] : 0.f; }
 }
 
+// engine-creation helpers: compact id of every occupied cell, then the S^3-sized resolution of nearest_occ
+__global__ void k_scatter_occ(const int* __restrict__ cells, int n, int* __restrict__ occ_id) {
+    const int o = blockIdx.x * blockDim.x + threadIdx.x;
+    if (o < n) occ_id[cells[o]] = o;
+}
+__global__ void k_build_cmask(const int* __restrict__ nearest, const int* __restrict__ occ_id, const uint16_t* __restrict__ occ_mask,
+                              unsigned long long ncell, uint16_t* __restrict__ cmask, int* __restrict__ occ_out) {
+    const unsigned long long k = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= ncell) return;
+    const int nk = nearest[k];
+    const int o = (nk >= 0 && (unsigned long long)nk < ncell) ? occ_id[nk] : -1;
+    cmask[k] = o < 0 ? (uint16_t)0 : occ_mask[o];
+    if (occ_out) occ_out[k] = o;
+}
+
 // K5: rotated cloud + weight as float4 (reference jly_goicp.cpp:750-756)
 __global__ void k_rotate(DevTables T, const float* __restrict__ R, float4* __restrict__ out) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1089,28 +1104,39 @@ extern "C" int goicp_engine_create(const goicp_engine_desc* d, goicp_engine** ou
         std::vector<int> mcls(d->Nm);
         for (int i = 0; i < d->Nm; i++) mcls[i] = cls_of(d->model_color[i]);
         if (cls.size() > 16) { h->err = "more than 16 distinct colour codes"; CR(GOICP_ERR_ARG); }
-        // compat mask per cell, resolving emptyCells -> cellPoints (reference jly_goicp.cpp:986-1000,1068-1092)
-        std::vector<uint16_t> cmask(ncell, 0);
-        std::vector<int> occ(ncell, -1), occ_id(ncell, -1), occ_ptr(1, 0), occ_pts;
+        // compat mask per cell, resolving emptyCells -> cellPoints (reference jly_goicp.cpp:986-1000,1068-1092): the per-occupied-
+        // cell masks are formed on the host (a few hundred cells), the S^3-sized gather through nearest_occ runs on the device
+        std::vector<int> occ_cells, occ_ptr(1, 0), occ_pts;
+        std::vector<uint16_t> occ_mask;
         for (size_t k = 0; k < ncell; k++) {
-            if (d->cell_color[k] == -2) continue;
-            occ_id[k] = (int)occ_ptr.size() - 1;
+            const int col = d->cell_color[k];
+            if (col == -2) continue;
+            occ_cells.push_back((int)k);
+            uint16_t m = 0;
+            if (col == -1) { for (int p = d->cell_ptr[k]; p < d->cell_ptr[k + 1]; p++) m |= (uint16_t)(1u << mcls[d->cell_idx[p]]); }
+            else if (known_prop(col)) { auto it = cls.find(col); if (it != cls.end()) m = (uint16_t)(1u << it->second); }
+            occ_mask.push_back(m);
             for (int p = d->cell_ptr[k]; p < d->cell_ptr[k + 1]; p++) occ_pts.push_back(d->cell_idx[p]);
             occ_ptr.push_back((int)occ_pts.size());
         }
-        for (size_t k = 0; k < ncell; k++) {
-            const int nk = d->nearest_occ[k];
-            if (nk < 0 || (size_t)nk >= ncell) { h->err = "nearest_occ out of range"; CR(GOICP_ERR_ARG); }
-            const int col = d->cell_color[nk];
-            uint16_t m = 0;
-            if (col == -1) { for (int p = d->cell_ptr[nk]; p < d->cell_ptr[nk + 1]; p++) m |= (uint16_t)(1u << mcls[d->cell_idx[p]]); }
-            else if (col != -2 && known_prop(col)) { auto it = cls.find(col); if (it != cls.end()) m = (uint16_t)(1u << it->second); }
-            cmask[k] = m;
-            occ[k] = occ_id[nk];
+        const int nOcc = (int)occ_cells.size();
+        int* p_near; CR(dev_upload(h, d->nearest_occ, ncell, &p_near));
+        int* p_occid; CR(dev_upload<int>(h, nullptr, ncell, &p_occid));
+        int* p_cells; CR(dev_upload(h, occ_cells.data(), (size_t)nOcc, &p_cells));
+        uint16_t* p_om; CR(dev_upload(h, occ_mask.data(), (size_t)nOcc, &p_om));
+        uint16_t* p_cm; CR(dev_upload<uint16_t>(h, nullptr, ncell, &p_cm));
+        int* p_occ = nullptr;
+        if (use_fpfh) CR(dev_upload<int>(h, nullptr, ncell, &p_occ));
+        CRH(hipMemsetAsync(p_occid, 0xFF, ncell * sizeof(int), h->stream));
+        if (nOcc) hipLaunchKernelGGL(k_scatter_occ, dim3((nOcc + 255) / 256), dim3(256), 0, h->stream, p_cells, nOcc, p_occid);
+        hipLaunchKernelGGL(k_build_cmask, dim3((unsigned)((ncell + 255) / 256)), dim3(256), 0, h->stream, p_near, p_occid, p_om, (unsigned long long)ncell, p_cm, p_occ);
+        CRH(hipGetLastError());
+        CRH(hipStreamSynchronize(h->stream));
+        {   // nearest_occ range check happened on the device (out-of-range entries resolve to "no occupied cell")
+            T.cmask = p_cm;
         }
-        uint16_t* p_cm; CR(dev_upload(h, cmask.data(), ncell, &p_cm)); T.cmask = p_cm;
         if (use_fpfh) {
-            int* p_occ; CR(dev_upload(h, occ.data(), ncell, &p_occ)); T.occ = p_occ;
+            T.occ = p_occ;
             int* p_op; CR(dev_upload(h, occ_ptr.data(), occ_ptr.size(), &p_op)); T.occ_ptr = p_op;
             int* p_oi; CR(dev_upload(h, occ_pts.data(), occ_pts.size(), &p_oi)); T.occ_pts = p_oi;
             float* p_mf; CR(dev_upload(h, d->model_fpfh, (size_t)GOICP_FPFH_BINS * d->Nm, &p_mf)); T.mfpfh = p_mf;

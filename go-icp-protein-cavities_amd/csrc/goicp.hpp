@@ -131,6 +131,7 @@ private:
     double icp_ms_ = 0;
     std::vector<float> normData_, minDis_;
     std::vector<int32_t> icp_id_data_, icp_id_model_, opt_id_data_, opt_id_model_;
+    std::vector<uint32_t> sort_key_, sort_a_, sort_b_;
     float OuterBnB();                      // reference jly_goicp.cpp:582-876
     float icp_run(Matrix& R, Matrix& t);   // reference jly_icp3d.hpp:197-311 (1-NN on the device)
     void neighborsWeights();               // reference jly_goicp.cpp:1453-1498

@@ -349,8 +349,24 @@ float GoICP::icp_run(Matrix& R, Matrix& t) {
         for (int i = 0; i < n; i++) { pts[i].dis = dsq[i]; pts[i].id_data = i; pts[i].id_model = ids[i]; }
         if (doTrim) {
             // qsort with a comparator that never reports equality (jly_icp3d.hpp:172-176,254); under glibc's merge
-            // sort ties keep their order, i.e. a stable sort by dis
-            std::stable_sort(pts.begin(), pts.end(), [](const Ref& a, const Ref& b) { return a.dis < b.dis; });
+            // sort ties keep their order, i.e. a stable sort by dis. dis is a non-negative float, so its bit pattern
+            // orders like the value: three stable counting passes (11+11+10 bits) give the same permutation.
+            std::vector<uint32_t>& key = sort_key_; std::vector<uint32_t>& ia = sort_a_; std::vector<uint32_t>& ib = sort_b_;
+            key.resize(n); ia.resize(n); ib.resize(n);
+            for (int i = 0; i < n; i++) { std::memcpy(&key[i], &dsq[i], 4); ia[i] = (uint32_t)i; }
+            uint32_t cnt[2048];
+            const int shifts[3] = {0, 11, 22}, bits[3] = {11, 11, 10};
+            for (int pass = 0; pass < 3; pass++) {
+                const uint32_t mask = (1u << bits[pass]) - 1u;
+                std::memset(cnt, 0, sizeof cnt);
+                for (int i = 0; i < n; i++) cnt[(key[ia[i]] >> shifts[pass]) & mask]++;
+                uint32_t run = 0;
+                for (uint32_t b = 0; b <= mask; b++) { const uint32_t c = cnt[b]; cnt[b] = run; run += c; }
+                for (int i = 0; i < n; i++) { const uint32_t id = ia[i]; ib[cnt[(key[id] >> shifts[pass]) & mask]++] = id; }
+                ia.swap(ib);
+            }
+            for (int i = 0; i < n; i++) { const int id = (int)ia[i]; tmp[i].dis = dsq[id]; tmp[i].id_data = id; tmp[i].id_model = ids[id]; }
+            pts.swap(tmp);
         }
         for (int i = 0; i < num; i++) {
             const int im = pts[i].id_model, id = pts[i].id_data;
