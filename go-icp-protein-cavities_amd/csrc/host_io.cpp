@@ -217,7 +217,8 @@ bool apply_transformation_protein(const std::string& output_txt, const std::stri
         std::string s[9];
         int n = 0;
         while (n < 9 && (ss >> s[n])) n++;
-        if (n >= 1 && s[0] == "@<TRIPOS>BOND") { out << s[0] << std::endl; state = 2; continue; }
+        // the reference prints the tag, then its line-oriented copy loop emits the (empty) rest of that line (transformation.cpp:505-520)
+        if (n >= 1 && s[0] == "@<TRIPOS>BOND") { out << s[0] << std::endl << std::endl; state = 2; continue; }
         if (n < 9) { out << line << std::endl; continue; }
         const double x = atof(s[2].c_str()), y = atof(s[3].c_str()), z = atof(s[4].c_str());
         const double nx = R[0] * x + R[1] * y + R[2] * z + t[0], ny = R[3] * x + R[4] * y + R[5] * z + t[1], nz = R[6] * x + R[7] * y + R[8] * z + t[2];

@@ -34,6 +34,13 @@ def copy_data():
     shutil.copyfile(os.path.join(REF, "demo", "output.txt"), os.path.join(DATA, "demo", "output.txt"))
     for f in ("model_rand.txt", "data_rand.txt"):
         shutil.copyfile(os.path.join(REF, "demo", f), os.path.join(DATA, "demo", f))
+    # post-processing known answers: protein chain, the reference's transformed copy and the aligned reference
+    import gzip
+    os.makedirs(os.path.join(DATA, "proteins"), exist_ok=True)
+    for src in ("chains/2x86_3_protein.mol2", "rot/rot_2x86_3_protein.mol2", "ref_proteins/2x86_3.1eq2_6/aligned_2x86_3_protein.mol2",
+                "rot/rot_2ktd_1_protein.mol2", "ref_proteins/2ktd_1.4imo_2/aligned_2ktd_1_protein.mol2"):
+        with open(os.path.join(REF, src), "rb") as fi, gzip.open(os.path.join(DATA, "proteins", os.path.basename(src) + ".gz"), "wb", compresslevel=9) as fo:
+            fo.write(fi.read())
     # bunny: model (35947 pts) + first 1000 data points, as float32 arrays (the .txt files are 3.7 MB)
     mb = read_txt_cloud(os.path.join(REF, "demo", "model_bunny.txt"))
     db = read_txt_cloud(os.path.join(REF, "demo", "data_bunny.txt"), limit=1000)

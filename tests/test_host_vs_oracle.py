@@ -65,3 +65,30 @@ def test_rmsd_known_answers():
     got = goicp_amd.compute_rmsd(os.path.join(d, "a.mol2"), os.path.join(d, "b.mol2"))
     want = np.float32(np.sqrt(np.float32(1 + 1 + 4 + 0) / 4))     # backbone atoms N, CA, C, O only (CB skipped)
     assert abs(got - want) < 1e-6
+
+
+def _gunzip(name, dst):
+    import gzip, shutil
+    with gzip.open(os.path.join(DATA, "proteins", name + ".gz"), "rb") as fi, open(dst, "wb") as fo:
+        shutil.copyfileobj(fi, fo)
+    return dst
+
+
+def test_rmsd_known_answers_on_shipped_proteins(tmp_path):
+    # Transformation::computeRMSD (transformation.cpp:453-464) on the shipped aligned / transformed proteins:
+    # SURVEY.md 8(c) known answers 1.73675334 (pair 1) and 13.9296408 (pair 2), float accumulation
+    d = str(tmp_path)
+    a1 = _gunzip("aligned_2x86_3_protein.mol2", os.path.join(d, "a1.mol2")); r1 = _gunzip("rot_2x86_3_protein.mol2", os.path.join(d, "r1.mol2"))
+    a2 = _gunzip("aligned_2ktd_1_protein.mol2", os.path.join(d, "a2.mol2")); r2 = _gunzip("rot_2ktd_1_protein.mol2", os.path.join(d, "r2.mol2"))
+    assert np.float32(goicp_amd.compute_rmsd(a1, r1)) == np.float32(1.73675334)
+    assert np.float32(goicp_amd.compute_rmsd(a2, r2)) == np.float32(13.9296408)
+
+
+def test_protein_transform_reproduces_shipped_file(tmp_path):
+    # Transformation::applyTransformationProtein (transformation.cpp:469-539) with the shipped output/similar1_rescaled.txt
+    # on chains/2x86_3_protein.mol2 -> rot/rot_2x86_3_protein.mol2, byte for byte
+    d = str(tmp_path)
+    chain = _gunzip("2x86_3_protein.mol2", os.path.join(d, "chain.mol2")); want = _gunzip("rot_2x86_3_protein.mol2", os.path.join(d, "want.mol2"))
+    out = os.path.join(d, "got.mol2")
+    assert goicp_amd.apply_transformation_protein(os.path.join(DATA, "output", "similar1_rescaled.txt"), chain, out)
+    assert open(out).read() == open(want).read()
