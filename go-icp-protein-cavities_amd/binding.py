@@ -181,7 +181,8 @@ class Engine:
                 J[i].init[k] = float(j["init"][k])
             J[i].init_lb = float(j.get("init_lb", 0.0)); J[i].max_pops = int(j.get("max_pops", 0))
         rc = self.L.goicp_engine_inner_bnb_batch(self.h, J, n, Rr)
-        self._chk(rc, "inner_bnb_batch")
+        if rc not in (4, 5):      # ERR_OVERFLOW / ERR_LIMIT are per-job outcomes reported in each result's status
+            self._chk(rc, "inner_bnb_batch")
         return [dict(val=np.float32(r.optErrorT), node=np.array(list(r.node), np.float32), found=int(r.found), status=int(r.status),
                      pops=int(r.pops), cube_evals=int(r.cube_evals)) for r in Rr]
 

@@ -1043,6 +1043,7 @@ static void pick_geometry(goicp_engine* h) {
     // k_inner_bnb keeps the top of its queue in LDS behind the residual rows (24 B per node)
     h->rbuf_floats = (int)(h->dyn_lds / sizeof(float));
     h->heap_lds_nodes = 2048;
+    { const char* e = getenv("GOICP_HEAP_LDS"); if (e && atoi(e) >= 0 && atoi(e) <= 2048) h->heap_lds_nodes = atoi(e); }   // test knob
     h->dyn_lds_bnb = h->dyn_lds + (size_t)h->heap_lds_nodes * sizeof(HeapNode);
     h->fp_lds = 0;
     if (h->T.use_fpfh && h->dyn_lds_bnb + (size_t)27 * Nd * sizeof(float) + sizeof(TileShm<1024>) + 1024 <= 160 * 1024) { h->fp_lds = 1; h->dyn_lds_bnb += (size_t)27 * Nd * sizeof(float); }
@@ -1083,6 +1084,7 @@ extern "C" int goicp_engine_create(const goicp_engine_desc* d, goicp_engine** ou
     T.use_compat = use_compat; T.use_fpfh = use_fpfh;
     { const char* e = getenv("GOICP_DBG"); T.dbg = e ? atoi(e) : 0; }
     { const char* e = getenv("GOICP_MAX_POPS"); if (e) h->max_pops = (unsigned)atoll(e); }
+    { const char* e = getenv("GOICP_HEAP_CAP"); if (e && atoi(e) >= 16) h->heap_cap = atoi(e); }      // test knob: small queue slabs
     T.exact = (d->parity_mode && d->Nd <= 1024) ? 1 : 0;   // 2*TC*Nd floats of LDS next to the static tile state and the LDS heap
     const size_t ncell = (size_t)d->S * d->S * d->S;
     float* p_dist; CR(dev_upload(h, d->dt_dist, ncell, &p_dist)); T.dist = p_dist;
@@ -1404,4 +1406,63 @@ extern "C" int goicp_engine_icp_nn(goicp_engine* h, const double* R9, const doub
     HIPCHK(h, hipMemcpyAsync(dist_sq, h->d_dist, (size_t)h->T.Nd * sizeof(float), hipMemcpyDeviceToHost, h->stream));
     HIPCHK(h, hipStreamSynchronize(h->stream));
     return GOICP_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// neighbour counts for the point weighting (GoICP::neighborsWeights, reference jly_goicp.cpp:1453-1498 with isNeighbor
+// :1097-1103): count_i = #{ j != i : sqrt(dx^2+dy^2+dz^2) < lim } with the differences formed in float and everything
+// else in double, exactly as the reference's pow/sqrt expression. O(Nd^2) per radius step -> one kernel per step.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_neighbor_counts(const float* __restrict__ xyz, int n, double lim, int* __restrict__ counts) {
+    __shared__ float sx[256], sy[256], sz[256];
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    float xi = 0.f, yi = 0.f, zi = 0.f;
+    if (i < n) { xi = xyz[3 * i]; yi = xyz[3 * i + 1]; zi = xyz[3 * i + 2]; }
+    int cnt = 0;
+    for (int base = 0; base < n; base += 256) {
+        const int j = base + threadIdx.x;
+        __syncthreads();
+        if (j < n) { sx[threadIdx.x] = xyz[3 * j]; sy[threadIdx.x] = xyz[3 * j + 1]; sz[threadIdx.x] = xyz[3 * j + 2]; }
+        __syncthreads();
+        const int m = min(256, n - base);
+        for (int q = 0; q < m; q++) {
+            const double dx = (double)(sx[q] - xi), dy = (double)(sy[q] - yi), dz = (double)(sz[q] - zi);
+            const double d = sqrt(dx * dx + dy * dy + dz * dz);
+            cnt += (base + q != i && d < lim) ? 1 : 0;
+        }
+    }
+    if (i < n) counts[i] = cnt;
+}
+
+struct goicp_nbr_ctx { int device; int n; float* d_xyz; int* d_cnt; };
+
+extern "C" int goicp_nbr_create(int device_id, const float* xyz, int n, goicp_nbr_ctx** out) {
+    if (!xyz || n <= 0 || !out) return GOICP_ERR_ARG;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || device_id < 0 || device_id >= ndev) return GOICP_ERR_NO_DEVICE;
+    if (hipSetDevice(device_id) != hipSuccess) return GOICP_ERR_NO_DEVICE;
+    goicp_nbr_ctx* c = new goicp_nbr_ctx();
+    c->device = device_id; c->n = n; c->d_xyz = nullptr; c->d_cnt = nullptr;
+    if (hipMalloc((void**)&c->d_xyz, (size_t)3 * n * sizeof(float)) != hipSuccess || hipMalloc((void**)&c->d_cnt, (size_t)n * sizeof(int)) != hipSuccess ||
+        hipMemcpy(c->d_xyz, xyz, (size_t)3 * n * sizeof(float), hipMemcpyHostToDevice) != hipSuccess) {
+        if (c->d_xyz) hipFree(c->d_xyz);
+        if (c->d_cnt) hipFree(c->d_cnt);
+        delete c; return GOICP_ERR_HIP;
+    }
+    *out = c;
+    return GOICP_OK;
+}
+extern "C" int goicp_nbr_count(goicp_nbr_ctx* c, double lim, int32_t* counts) {
+    if (!c || !counts) return GOICP_ERR_ARG;
+    if (hipSetDevice(c->device) != hipSuccess) return GOICP_ERR_HIP;
+    hipLaunchKernelGGL(k_neighbor_counts, dim3((c->n + 255) / 256), dim3(256), 0, 0, c->d_xyz, c->n, lim, c->d_cnt);
+    if (hipGetLastError() != hipSuccess) return GOICP_ERR_HIP;
+    if (hipMemcpy(counts, c->d_cnt, (size_t)c->n * sizeof(int), hipMemcpyDeviceToHost) != hipSuccess) return GOICP_ERR_HIP;
+    return GOICP_OK;
+}
+extern "C" void goicp_nbr_destroy(goicp_nbr_ctx* c) {
+    if (!c) return;
+    hipSetDevice(c->device);
+    hipFree(c->d_xyz); hipFree(c->d_cnt);
+    delete c;
 }

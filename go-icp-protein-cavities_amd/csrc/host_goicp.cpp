@@ -232,22 +232,41 @@ void GoICP::neighborsWeights() {
     int maxN = 0, minN = 100;
     float radius = 0.035f;
     int guard = 0;
+    // O(Nd^2) pair tests per radius step: on the device for large clouds (same float/double arithmetic, integer counts)
+    goicp_nbr_ctx* nb = nullptr;
+    std::vector<int32_t> cnts;
+    if (Nd >= 1024) {
+        std::vector<float> xyz((size_t)3 * Nd);
+        for (int i = 0; i < Nd; i++) { xyz[3 * i] = pData[i].x; xyz[3 * i + 1] = pData[i].y; xyz[3 * i + 2] = pData[i].z; }
+        if (goicp_nbr_create(device_id, xyz.data(), Nd, &nb) != GOICP_OK) nb = nullptr;
+        cnts.resize(Nd);
+    }
     while (maxN < 19) {
         if (Nd < 20 && ++guard > 100000) break;      // the reference never terminates for Nd < 20
         const double lim = (double)std::sqrt(radius);
-        for (int i = 0; i < Nd; i++) {
-            int cnt = 0;
-            for (int j = 0; j < Nd; j++) {
-                if (j == i) continue;
-                const double dx = (double)(pData[j].x - pData[i].x), dy = (double)(pData[j].y - pData[i].y), dz = (double)(pData[j].z - pData[i].z);
-                if (std::sqrt(dx * dx + dy * dy + dz * dz) < lim) cnt++;
+        if (nb && goicp_nbr_count(nb, lim, cnts.data()) == GOICP_OK) {
+            for (int i = 0; i < Nd; i++) {
+                const int cnt = cnts[i];
+                pData[i].neighbors = cnt;
+                if (cnt > maxN) maxN = cnt;
+                if (cnt < minN) minN = cnt;
             }
-            pData[i].neighbors = cnt;
-            if (cnt > maxN) maxN = cnt;
-            if (cnt < minN) minN = cnt;
+        } else {
+            for (int i = 0; i < Nd; i++) {
+                int cnt = 0;
+                for (int j = 0; j < Nd; j++) {
+                    if (j == i) continue;
+                    const double dx = (double)(pData[j].x - pData[i].x), dy = (double)(pData[j].y - pData[i].y), dz = (double)(pData[j].z - pData[i].z);
+                    if (std::sqrt(dx * dx + dy * dy + dz * dz) < lim) cnt++;
+                }
+                pData[i].neighbors = cnt;
+                if (cnt > maxN) maxN = cnt;
+                if (cnt < minN) minN = cnt;
+            }
         }
         radius = (float)(radius + 0.001);
     }
+    if (nb) goicp_nbr_destroy(nb);
     if (minN == 0) minN = 1;
     for (int i = 0; i < Nd; i++) {
         if (pData[i].neighbors == 0) pData[i].neighbors = 1;

@@ -132,6 +132,13 @@ int goicp_engine_stats(const goicp_engine* h, uint64_t* cube_evals, uint64_t* lo
 /* opaque hipStream_t of the handle, for callers that time with their own HIP events */
 void* goicp_engine_stream(const goicp_engine* h);
 
+/* ---- point-weight precompute (GoICP::neighborsWeights, reference jly_goicp.cpp:1453-1498) ----
+ * counts[i] = #{ j != i : ||p_j - p_i|| < lim } with the reference's float/double mixing; one call per radius step. */
+typedef struct goicp_nbr_ctx goicp_nbr_ctx;
+int  goicp_nbr_create(int device_id, const float* xyz, int n, goicp_nbr_ctx** out);
+int  goicp_nbr_count(goicp_nbr_ctx* ctx, double lim, int32_t* counts);
+void goicp_nbr_destroy(goicp_nbr_ctx* ctx);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,108 @@
+"""GPU (-m gpu): boundary behaviour of the C ABI -- empty and ragged inputs, argument errors (status codes, never exits),
+pop budgets, queue-slab regrowth."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import goicp_amd
+from goicp_amd.binding import BnbJob, BnbResult
+from helpers import load_clouds, load_hotpath
+from test_gpu_parity import engine_from_hotpath
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def eng():
+    H = load_hotpath("pair1_default"); P = load_clouds("pair1")
+    e = engine_from_hotpath(H, P)
+    e.set_rotation(0, H["call_R"][0])
+    yield e, H, P
+    e.close()
+
+
+def test_empty_and_ragged_cube_lists(eng):
+    e, H, P = eng
+    ub, lb = e.eval_cubes(0, -1, np.zeros((0, 4), np.float32))
+    assert len(ub) == 0 and len(lb) == 0
+    cubes = H["cubes"][:23, 1:5].astype(np.float32)          # 23 = 2 full tiles of 8 + a tail of 7
+    ub_all, lb_all = e.eval_cubes(0, 2, cubes)
+    for n in (1, 7, 8, 9, 17):
+        ub, lb = e.eval_cubes(0, 2, cubes[:n])
+        assert np.array_equal(ub, ub_all[:n]) and np.array_equal(lb, lb_all[:n])
+    # order independence: a cube's bounds do not depend on its tile mates
+    perm = np.random.default_rng(0).permutation(23)
+    ubp, lbp = e.eval_cubes(0, 2, cubes[perm])
+    assert np.array_equal(ubp, ub_all[perm]) and np.array_equal(lbp, lb_all[perm])
+
+
+def test_argument_errors_are_status_codes(eng):
+    e, H, P = eng
+    L = e.L
+    cubes = np.zeros((8, 4), np.float32); ub = np.zeros(8, np.float32); lb = np.zeros(8, np.float32)
+    p = lambda a: a.ctypes.data_as(C.c_void_p)
+    assert L.goicp_engine_eval_cubes(e.h, 99, -1, p(cubes), 8, p(ub), p(lb)) == 1          # bad slot
+    assert L.goicp_engine_eval_cubes(e.h, 0, 20, p(cubes), 8, p(ub), p(lb)) == 1           # rot level >= MAXROTLEVEL
+    assert L.goicp_engine_eval_cubes(e.h, 0, -1, None, 8, p(ub), p(lb)) == 1               # null buffer
+    assert L.goicp_engine_set_rotation(e.h, -1, p(np.eye(3, dtype=np.float32))) == 1
+    J = (BnbJob * 1)(); R = (BnbResult * 1)()
+    J[0].rot_level = 25
+    assert L.goicp_engine_inner_bnb_batch(e.h, J, 1, R) == 1
+    assert L.goicp_engine_inner_bnb_batch(e.h, J, 0, R) == 0                               # empty batch is fine
+
+
+def test_unsupported_configurations_fail_at_create():
+    H = load_hotpath("pair1_default"); P = load_clouds("pair1")
+    base = dict(S=int(H["geom"][7]), geom4=(H["geom"][0], H["geom"][2], H["geom"][4], H["geom"][6]), dist=H["dist"], data_xyz=P["s"], weights=H["weights"],
+                maxrotdis=H["maxrotdis"], model_xyz=P["t"], inlier_num=int(H["inlierNum"]))
+    with pytest.raises(goicp_amd.EngineError):          # penalties requested without cell tables
+        goicp_amd.Engine(reg=0.0005, **base)
+    with pytest.raises(goicp_amd.EngineError):          # inlierNum out of range for a trimmed run
+        goicp_amd.Engine(do_trim=True, **dict(base, inlier_num=0))
+    with pytest.raises(goicp_amd.EngineError):          # no such device
+        goicp_amd.Engine(device_id=63, **base)
+    big = np.zeros((9000, 3), np.float32)
+    with pytest.raises(goicp_amd.EngineError):          # register-resident cloud limit (8192 points)
+        goicp_amd.Engine(**dict(base, data_xyz=big, weights=np.ones(9000, np.float32), maxrotdis=np.zeros(20 * 9000, np.float32), inlier_num=9000))
+
+
+def test_more_than_16_colour_codes_is_rejected():
+    H = load_hotpath("pair1_default"); P = load_clouds("pair1")
+    S = int(H["geom"][7])
+    near = (H["nearest3"][:, 2].astype(np.int64) * S + H["nearest3"][:, 1]) * S + H["nearest3"][:, 0]
+    dc = np.arange(len(P["s"]), dtype=np.int32) % 40 + 100
+    with pytest.raises(goicp_amd.EngineError):
+        goicp_amd.Engine(S=S, geom4=(H["geom"][0], H["geom"][2], H["geom"][4], H["geom"][6]), dist=H["dist"], data_xyz=P["s"], weights=H["weights"],
+                         maxrotdis=H["maxrotdis"], model_xyz=P["t"], inlier_num=int(H["inlierNum"]), reg=0.0005, nearest=near, cell_color=H["cellc"],
+                         cell_ptr=H["cell_ptr"], cell_idx=H["cell_idx"], model_color=P["tc"], data_color=dc)
+
+
+def test_pop_budget_and_rerun(eng):
+    e, H, P = eng
+    cfg = H["cfg"]; init = tuple(np.float32(cfg[5:9]))
+    jobs = [dict(R=H["call_R"][k], level=int(H["call_level"][k]), E=H["call_E"][k], sse=np.float32(H["sse"]), init=init) for k in range(len(H["call_level"]))]
+    full = e.inner_bnb_batch(jobs)
+    k = int(np.argmax([r["pops"] for r in full]))
+    assert full[k]["status"] == 0 and full[k]["pops"] > 20
+    capped = e.inner_bnb(max_pops=10, **jobs[k])
+    assert capped["status"] == 5 and capped["pops"] == 11          # GOICP_ERR_LIMIT, stopped right after the budget
+    again = e.inner_bnb(**jobs[k])                                  # unbounded again: same search, same answer
+    assert again["status"] == 0 and again["val"] == full[k]["val"] and again["pops"] == full[k]["pops"] and np.array_equal(again["node"], full[k]["node"])
+
+
+def test_queue_slab_regrowth_gives_the_same_answer(monkeypatch):
+    """With a 32-node queue slab (test knob) and only 8 nodes in LDS, every longer search overflows and is re-run alone on
+    16x larger slabs; the results must still be the reference's known answers, bit for bit."""
+    monkeypatch.setenv("GOICP_HEAP_CAP", "32"); monkeypatch.setenv("GOICP_HEAP_LDS", "8")
+    H = load_hotpath("pair1_default"); P = load_clouds("pair1")
+    e = engine_from_hotpath(H, P)
+    cfg = H["cfg"]; init = tuple(np.float32(cfg[5:9]))
+    jobs = [dict(R=H["call_R"][k], level=int(H["call_level"][k]), E=H["call_E"][k], sse=np.float32(H["sse"]), init=init) for k in range(len(H["call_level"]))]
+    res = e.inner_bnb_batch(jobs)
+    assert max(r["pops"] for r in res) > 40            # long enough that queues exceed 24 nodes and the regrowth path runs
+    for k, r in enumerate(res):
+        assert r["status"] == 0 and r["val"] == H["call_val"][k]
+        if r["found"]:
+            assert np.array_equal(r["node"], H["call_node"][k])
+    e.close()

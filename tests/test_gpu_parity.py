@@ -303,3 +303,13 @@ def test_batch_driver_on_one_gpu(tmp_path):
     G = load_register()
     assert np.float32(allr[0, 13]) == np.float32(G["pair1_default"]["error"]) and np.float32(allr[1, 13]) == np.float32(G["pair2_default"]["error"])
     assert int(allr[0, 14]) == 133 and int(allr[1, 14]) == 118
+
+
+def test_neighbour_weights_on_device_match_oracle():
+    """ponderation=1 on a 3000-point cloud: the O(Nd^2) neighbour counts run on the device (Nd >= 1024); weights must be bit-equal."""
+    P = synth_pair(3000, seed=99)
+    v, _ = cfg_vector(distTransSize=40, ponderation=1, regularization=0.0)
+    o = oracle_for(P, v); o.initialize()
+    g = goicp_amd.GoICP(v); g.set_clouds(P["t"], P["s"]); g.build_dt(); g.initialize()
+    assert np.array_equal(g.weights(), o.weights())
+    g.close()
