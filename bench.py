@@ -22,7 +22,6 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
-sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 N_POINTS = 5000
 DT_SIZE = 300
@@ -71,7 +70,7 @@ def main():
     dev = torch.device("cuda", local)
 
     import goicp_amd
-    from helpers import synth_pair
+    from goicp_amd.synth import synth_pair
     goicp_amd.load_library()                  # fails loudly if the HIP extension is missing
 
     nd = args.points
@@ -235,7 +234,7 @@ def cpu_baseline(g, P, cfg, args, reg):
     """Times the reference's own InnerBnB (oracle/_ref) on the host cores of this box, replaying the first InnerBnB calls of the
     GPU registration (same rotations, levels and incumbents => identical searches) until ~cpu_seconds of CPU time are spent."""
     from oracle import refbind
-    from helpers import rot_cloud
+    from goicp_amd.synth import rot_cloud
     jobs = g.job_log() if reg is not None else []
     if not jobs:
         return None
