@@ -7,12 +7,12 @@
 // Kernels
 //   k_inner_bnb   one workgroup = one whole InnerBnB call (reference jly_goicp.cpp:286-579): the data
 //                 cloud is rotated in-kernel and lives in registers (PPT points per lane), each queue pop
-//                 sweeps the 8 child cubes (8*Nd DT gathers), selects the inliers with an LDS radix select,
+//                 sweeps the 8 child cubes (8*Nd DT gathers), finds the inlier threshold with an LDS histogram select,
 //                 evaluates the 27 shared corner-lattice penalty terms, and lane 0 replays the reference's
 //                 prune/push decisions on a binary heap that reproduces std::priority_queue's order.
 //   k_eval_cubes  the same sweep for an arbitrary list of cubes (8 cubes per workgroup), for callers that
 //                 drive the queue themselves and for the cube-evals/s benchmark.
-//   k_rotate, k_corner_terms, k_point_eval, k_icp_nn   small helpers (see goicp_engine.h).
+//   k_rotate, k_corner_terms, k_point_eval, k_icp_nn, k_fpfh_table, k_build_cmask, k_neighbor_counts   helpers (see goicp_engine.h).
 //
 // Data layout in HBM (staged once per engine): DT distance grid float[S^3] x-fastest; compat mask
 // uint16[S^3] (bit c set <=> a data point of colour class c is compatible with the nearest occupied cell of
@@ -91,16 +91,6 @@ __device__ __forceinline__ int clamp_cell(int x, int S) {
     return r;
 }
 __device__ __forceinline__ int grid_off(int x, int S) { return x < 0 ? x : (x >= S ? x - S + 1 : 0); }
-__device__ __forceinline__ int dt_axis(float v, double mn, double scale, int S, int& off) {
-    const int x = cell_of(v, mn, scale);
-    off = grid_off(x, S);
-    return min(max(x, 0), S - 1);
-}
-__device__ __forceinline__ float dt_ext(int ax, int ay, int az) {
-    float ext = 0.f;
-    if ((ax | ay | az) != 0) { const float a = (float)ax, b = (float)ay, c = (float)az; ext = sqrtf(a * a + b * b + c * c); }
-    return ext;
-}
 // extension length from UNCLAMPED cell coordinates (0 when the cell is inside the grid)
 __device__ __forceinline__ float dt_ext_raw(int x, int y, int z, int S) {
     float ext = 0.f;
@@ -1006,14 +996,14 @@ extern "C" const char* goicp_engine_last_error(const goicp_engine* h) { return h
 
 extern "C" void goicp_engine_destroy(goicp_engine* h) {
     if (!h) return;
-    hipSetDevice(h->device);
-    for (void* p : h->allocs) hipFree(p);
-    if (h->d_heaps) hipFree(h->d_heaps);
-    if (h->d_heap_big) hipFree(h->d_heap_big);
-    if (h->d_fpscratch) hipFree(h->d_fpscratch);
-    if (h->ev0) hipEventDestroy(h->ev0);
-    if (h->ev1) hipEventDestroy(h->ev1);
-    if (h->stream) hipStreamDestroy(h->stream);
+    (void)hipSetDevice(h->device);
+    for (void* p : h->allocs) (void)hipFree(p);
+    if (h->d_heaps) (void)hipFree(h->d_heaps);
+    if (h->d_heap_big) (void)hipFree(h->d_heap_big);
+    if (h->d_fpscratch) (void)hipFree(h->d_fpscratch);
+    if (h->ev0) (void)hipEventDestroy(h->ev0);
+    if (h->ev1) (void)hipEventDestroy(h->ev1);
+    if (h->stream) (void)hipStreamDestroy(h->stream);
     delete h;
 }
 
@@ -1230,7 +1220,7 @@ extern "C" int goicp_engine_set_rotation(goicp_engine* h, int slot, const float*
 static int ensure_fpscratch(goicp_engine* h, size_t blocks) {
     if (!h->T.use_fpfh) return GOICP_OK;
     if (blocks <= h->fp_blocks) return GOICP_OK;
-    if (h->d_fpscratch) { HIPCHK(h, hipStreamSynchronize(h->stream)); hipFree(h->d_fpscratch); h->d_fpscratch = nullptr; h->fp_blocks = 0; }
+    if (h->d_fpscratch) { HIPCHK(h, hipStreamSynchronize(h->stream)); (void)hipFree(h->d_fpscratch); h->d_fpscratch = nullptr; h->fp_blocks = 0; }
     HIPCHK(h, hipMalloc((void**)&h->d_fpscratch, blocks * NLMAX * (size_t)h->T.Nd * sizeof(float)));
     h->fp_blocks = blocks;
     return GOICP_OK;
@@ -1286,7 +1276,7 @@ extern "C" int goicp_engine_eval_cubes(goicp_engine* h, int slot, int rot_level,
         HIPCHK(h, hipMemcpyAsync(ub + off, h->d_ub, (size_t)m * sizeof(float), hipMemcpyDeviceToHost, h->stream));
         HIPCHK(h, hipMemcpyAsync(lb + off, h->d_lb, (size_t)m * sizeof(float), hipMemcpyDeviceToHost, h->stream));
         HIPCHK(h, hipStreamSynchronize(h->stream));
-        float ms = 0.f; hipEventElapsedTime(&ms, h->ev0, h->ev1); h->kernel_ms += ms;
+        float ms = 0.f; (void)hipEventElapsedTime(&ms, h->ev0, h->ev1); h->kernel_ms += ms;
     }
     return GOICP_OK;
 }
@@ -1315,7 +1305,7 @@ extern "C" int goicp_engine_corner_terms(goicp_engine* h, int slot, const float*
 static int ensure_heaps(goicp_engine* h, size_t jobs) {
     // per-job queue slabs of the batch path (fixed capacity; a job that outgrows its slab is re-run alone on the big slab)
     if (h->d_heaps && jobs <= h->heap_jobs) return GOICP_OK;
-    if (h->d_heaps) { HIPCHK(h, hipStreamSynchronize(h->stream)); hipFree(h->d_heaps); h->d_heaps = nullptr; }
+    if (h->d_heaps) { HIPCHK(h, hipStreamSynchronize(h->stream)); (void)hipFree(h->d_heaps); h->d_heaps = nullptr; }
     HIPCHK(h, hipMalloc((void**)&h->d_heaps, jobs * (size_t)h->heap_cap * sizeof(HeapNode)));
     h->heap_jobs = jobs;
     return GOICP_OK;
@@ -1323,7 +1313,7 @@ static int ensure_heaps(goicp_engine* h, size_t jobs) {
 
 static int ensure_big_heap(goicp_engine* h, int cap) {
     if (h->d_heap_big && cap <= h->heap_big_cap) return GOICP_OK;
-    if (h->d_heap_big) { HIPCHK(h, hipStreamSynchronize(h->stream)); hipFree(h->d_heap_big); h->d_heap_big = nullptr; }
+    if (h->d_heap_big) { HIPCHK(h, hipStreamSynchronize(h->stream)); (void)hipFree(h->d_heap_big); h->d_heap_big = nullptr; }
     HIPCHK(h, hipMalloc((void**)&h->d_heap_big, (size_t)cap * sizeof(HeapNode)));
     h->heap_big_cap = cap;
     return GOICP_OK;
@@ -1341,7 +1331,7 @@ static int run_bnb(goicp_engine* h, const goicp_bnb_job* jobs, int njobs, goicp_
     HIPCHK(h, hipEventRecord(h->ev1, h->stream));
     HIPCHK(h, hipMemcpyAsync(results, h->d_results, (size_t)njobs * sizeof(goicp_bnb_result), hipMemcpyDeviceToHost, h->stream));
     HIPCHK(h, hipStreamSynchronize(h->stream));
-    float ms = 0.f; hipEventElapsedTime(&ms, h->ev0, h->ev1); h->kernel_ms += ms;
+    float ms = 0.f; (void)hipEventElapsedTime(&ms, h->ev0, h->ev1); h->kernel_ms += ms;
     return GOICP_OK;
 }
 
@@ -1445,8 +1435,8 @@ extern "C" int goicp_nbr_create(int device_id, const float* xyz, int n, goicp_nb
     c->device = device_id; c->n = n; c->d_xyz = nullptr; c->d_cnt = nullptr;
     if (hipMalloc((void**)&c->d_xyz, (size_t)3 * n * sizeof(float)) != hipSuccess || hipMalloc((void**)&c->d_cnt, (size_t)n * sizeof(int)) != hipSuccess ||
         hipMemcpy(c->d_xyz, xyz, (size_t)3 * n * sizeof(float), hipMemcpyHostToDevice) != hipSuccess) {
-        if (c->d_xyz) hipFree(c->d_xyz);
-        if (c->d_cnt) hipFree(c->d_cnt);
+        if (c->d_xyz) (void)hipFree(c->d_xyz);
+        if (c->d_cnt) (void)hipFree(c->d_cnt);
         delete c; return GOICP_ERR_HIP;
     }
     *out = c;
@@ -1462,7 +1452,7 @@ extern "C" int goicp_nbr_count(goicp_nbr_ctx* c, double lim, int32_t* counts) {
 }
 extern "C" void goicp_nbr_destroy(goicp_nbr_ctx* c) {
     if (!c) return;
-    hipSetDevice(c->device);
-    hipFree(c->d_xyz); hipFree(c->d_cnt);
+    (void)hipSetDevice(c->device);
+    (void)hipFree(c->d_xyz); (void)hipFree(c->d_cnt);
     delete c;
 }
