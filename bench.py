@@ -57,7 +57,7 @@ def main():
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--no-register", action="store_true", help="skip the end-to-end registration leg")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
-    ap.add_argument("--cavity-pairs", type=int, default=32, help="cavity-like pairs registered per rank")
+    ap.add_argument("--cavity-pairs", type=int, default=8, help="cavity-like pairs registered per rank")
     ap.add_argument("--cavity-threads", type=int, default=8, help="host threads (= concurrent registrations, one engine + stream each) per rank")
     args = ap.parse_args()
 
