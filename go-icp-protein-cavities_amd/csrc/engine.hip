@@ -163,6 +163,66 @@ __device__ __forceinline__ void hist_add(unsigned* row, unsigned key, bool take,
     if (take && key != k0) atomicAdd(&row[key], 1u);
 }
 
+// ---------------------------------------------------------------------------------------------
+// intro_select of the reference (jly_sorting.hpp:34-313) with its exact swap sequence, run by ONE lane on a residual row in
+// LDS. Parity mode uses it for trimmed runs of small clouds: the permutation it leaves behind fixes the order of the
+// float sums that follow (jly_goicp.cpp:389-415), so the bounds come out bit-identical to the reference's.
+// ---------------------------------------------------------------------------------------------
+__device__ inline int sel_pivot_ends(const float* d, int s, int e) {
+    const int m = (s + e) / 2;
+    if (d[s] < d[e]) return d[m] < d[s] ? s : (d[m] < d[e] ? m : e);
+    return d[m] < d[e] ? e : (d[m] < d[s] ? m : s);
+}
+__device__ inline int sel_med3(const float* d, int s) {
+    if (d[s] < d[s + 2]) return d[s + 1] < d[s] ? s : (d[s + 1] < d[s + 2] ? s + 1 : s + 2);
+    return d[1] < d[2] ? s + 2 : (d[1] < d[0] ? s + 1 : s);            // absolute indices 0..2, as in jly_sorting.hpp:74-80
+}
+__device__ inline int sel_med5(float* d, int s) {
+    float* q = d + s; float t;
+    if (q[0] > q[1]) { t = q[0]; q[0] = q[1]; q[1] = t; }
+    if (q[2] > q[3]) { t = q[2]; q[2] = q[3]; q[3] = t; }
+    if (q[0] < q[2]) { t = q[4]; q[4] = q[0]; if (t < q[1]) q[0] = t; else { q[0] = q[1]; q[1] = t; } }
+    else { t = q[4]; q[4] = q[2]; if (t < q[3]) q[2] = t; else { q[2] = q[3]; q[3] = t; } }
+    if (q[0] < q[2]) return q[1] < q[2] ? s + 1 : s + 2;
+    return q[0] < q[3] ? s : s + 3;
+}
+__device__ inline int sel_median_of_medians(float* d, int s, int e) {
+    for (;;) {                                  // the reference recurses on the block of medians it has just moved to the front
+        const int len = e - s + 1, groups = len / 5 + (len % 5 != 0);
+        int g = s, i = 0, mi; float t;
+        for (; i + 1 < groups; i++, g += 5) { mi = sel_med5(d, g); t = d[s + i]; d[s + i] = d[mi]; d[mi] = t; }
+        const int rest = e - g + 1;
+        mi = (rest == 3 || rest == 4) ? sel_med3(d, g) : (rest == 5 ? sel_med5(d, g) : g);
+        t = d[s + i]; d[s + i] = d[mi]; d[mi] = t;
+        if (groups > 5) { e = s + groups - 1; continue; }
+        return (groups == 3 || groups == 4) ? sel_med3(d, s) : (groups == 5 ? sel_med5(d, s) : s);
+    }
+}
+__device__ inline void dev_intro_select(float* d, int s, int e, int k) {
+    int prev = e - s + 1, tries = 0; bool quick = true; float t;
+    for (;;) {
+        if (s >= e) return;
+        if (e - s <= 5) {
+            for (int i = s + 1; i <= e; i++) for (int j = i; j > s && d[j - 1] > d[j]; j--) { t = d[j - 1]; d[j - 1] = d[j]; d[j] = t; }
+            return;
+        }
+        if (quick && tries++ == 5) { const int len = e - s + 1; if (len * 2 > prev) quick = false; prev = len; tries = 0; }
+        const int pi = quick ? sel_pivot_ends(d, s, e) : sel_median_of_medians(d, s, e);
+        if (pi != s) { t = d[s]; d[s] = d[pi]; d[pi] = t; }
+        const float piv = d[s];
+        int lo = s + 1, hi = e;
+        for (;;) {
+            while (lo < hi && piv >= d[lo]) ++lo;
+            while (lo < hi && piv <= d[hi]) --hi;
+            if (lo >= hi) break;
+            t = d[lo]; d[lo] = d[hi]; d[hi] = t;
+        }
+        const int sp = d[lo] < piv ? lo : lo - 1;
+        d[s] = d[sp]; d[sp] = piv;
+        if (sp < k) s = sp + 1; else if (sp > k) e = sp - 1; else return;
+    }
+}
+
 template <int BLOCK>
 struct TileShm {
     float cube[TC][4];        // x, y, z, w
@@ -239,6 +299,38 @@ __device__ __forceinline__ void sweep_tile(const DevTables& T, TileShm<BLOCK>& s
             if (d < 0.f) d = 0.f;
             r[j][m] = d;
         }
+    }
+    if (BLOCK * PPT <= 1024 && T.exact && T.doTrim) {
+        // parity mode, trimmed: residual rows to LDS, one lane per cube runs the reference's selection (same swaps, same final
+        // order), then the inlier sums are taken sequentially in float over that order -- bit-exact with jly_goicp.cpp:384-415
+#pragma unroll
+        for (int m = 0; m < PPT; m++) {
+            const int i = tid + m * BLOCK;
+            if (i < Nd) {
+#pragma unroll
+                for (int j = 0; j < TC; j++) rbuf[j * Nd + i] = r[j][m];
+            }
+        }
+        __syncthreads();
+        if (tid < TC) dev_intro_select(rbuf + tid * Nd, 0, Nd - 1, T.inlierNum - 1);
+        __syncthreads();
+        if (tid < 2 * TC) {
+            const int j = tid & (TC - 1);
+            const bool is_lb = tid >= TC;
+            const float* rr = rbuf + j * Nd;
+            const float sub = is_lb ? sh.mtd[j] : 0.f;
+            const bool sq = T.norm == 2, lin = T.norm == 1;
+            float acc = 0.f;
+            for (int i = 0; i < T.inlierNum; i++) {
+                const float e = rr[i] - sub;                       // (d - 0 == d exactly for the ub chain)
+                float term = sq ? e * e : (lin ? e : 0.f);
+                if (is_lb && !(e > 0.f)) term = 0.f;
+                acc += term;
+            }
+            if (is_lb) sh.lb[j] = acc; else sh.ub[j] = acc;
+        }
+        __syncthreads();
+        return;
     }
     if (T.exact && !T.doTrim) {
         // reference order: float, sequential over the point index (bit-exact with jly_goicp.cpp:393-415). Every lane first
@@ -1029,7 +1121,7 @@ static void pick_geometry(goicp_engine* h) {
     else if (Nd <= 4096) { h->block = 1024; h->ppt = 4; }
     else if (Nd <= 5120) { h->block = 1024; h->ppt = 5; }
     else { h->block = 512; h->ppt = 16; }
-    h->dyn_lds = (h->T.exact && !h->T.doTrim) ? (size_t)2 * TC * Nd * sizeof(float) : 0;      // ub and lb addend rows
+    h->dyn_lds = h->T.exact ? (size_t)2 * TC * Nd * sizeof(float) : 0;      // ub and lb addend rows (untrimmed) / residual rows (trimmed)
     // k_inner_bnb keeps the top of its queue in LDS behind the residual rows (24 B per node)
     h->rbuf_floats = (int)(h->dyn_lds / sizeof(float));
     h->heap_lds_nodes = 2048;

@@ -47,7 +47,7 @@ def close(a, b, exact, n=None):
 @pytest.mark.parametrize("name", HOT)
 def test_eval_cubes_against_reference_tables(name):
     H = load_hotpath(name); P = load_clouds("pair2" if name.startswith("pair2") else "pair1")
-    exact = "trim" not in name
+    exact = True          # Nd = 238..247 <= 1024: parity mode covers untrimmed AND trimmed runs (device intro_select)
     e = engine_from_hotpath(H, P)
     cubes = H["cubes"]
     for k in range(len(H["call_level"])):
@@ -78,7 +78,7 @@ def test_corner_terms_against_reference(name):
 @pytest.mark.parametrize("name", HOT)
 def test_inner_bnb_against_reference(name):
     H = load_hotpath(name); P = load_clouds("pair2" if name.startswith("pair2") else "pair1")
-    exact = "trim" not in name
+    exact = True
     e = engine_from_hotpath(H, P)
     cfg = H["cfg"]
     init = tuple(np.float32(cfg[5:9]))
@@ -130,7 +130,7 @@ def test_register_against_reference_known_answers(name):
     g.set_clouds(P["t"], P["s"], P["tc"], P["sc"], P["tf"], P["sf"])
     g.build_dt()
     out = g.register()
-    exact = "trim" not in name
+    exact = True          # parity mode is bit-exact for trimmed runs too when Nd <= 1024
     assert np.abs(out["R"] - np.array(G["R"])).max() < 1e-5 and np.abs(out["t"] - np.array(G["t"])).max() < 1e-5
     assert out["comp"] == G["comp"]
     if exact:
@@ -153,6 +153,22 @@ def test_register_pair2_default_known_answer():
     # same number of translation-queue pops as the reference (counted by oracle/ref_shim.cpp), 8 cubes per expanded node
     assert out["stats"]["trans_pops"] == G["trans_pops"] == 339873 and out["stats"]["cube_evals"] == 2610920
     g.close()
+
+
+def test_register_demo_rand_known_answers_gpu():
+    """Upstream demo clouds (100 points, 100^3 DT): untrimmed and trimFraction 0.1, both bit-exact in parity mode."""
+    from oracle.refbind import read_txt_cloud
+    regs = load_register()
+    D = os.path.join(GOLDEN, "data", "demo")
+    mr = read_txt_cloud(os.path.join(D, "model_rand.txt")); dr = read_txt_cloud(os.path.join(D, "data_rand.txt"))
+    for nm in ("rand_untrimmed", "rand_trim"):
+        G = regs[nm]
+        g = goicp_amd.GoICP(cfg_vector(**G["cfg"])[0]); g.set_clouds(mr, dr); g.build_dt()
+        out = g.register()
+        assert float(out["error"]) == G["error"], (nm, out["error"], G["error"])
+        assert np.abs(out["R"] - np.array(G["R"])).max() < 1e-5 and np.abs(out["t"] - np.array(G["t"])).max() < 1e-5
+        assert out["stats"]["trans_pops"] == G["trans_pops"]
+        g.close()
 
 
 def test_speculative_batching_does_not_change_the_result():
@@ -180,7 +196,7 @@ def test_synthetic_cloud_against_oracle(n, S, trim):
     e = goicp_amd.Engine(S=S, geom4=(o.geom[0], o.geom[2], o.geom[4], o.geom[6]), dist=dist, data_xyz=P["s"], weights=o.weights(),
                          maxrotdis=o.maxrotdis(), model_xyz=P["t"], inlier_num=o.inlier_num(), do_trim=trim >= 0.001, norm=2, parity_mode=1)
     rng = np.random.default_rng(n + S)
-    exact = trim < 0.001 and n <= 1024
+    exact = n <= 1024
     for it in range(3):
         R = o.axis_angle(rng.uniform(-2, 2, 3).astype(np.float32))
         o.rotate(R); e.set_rotation(it, R)
