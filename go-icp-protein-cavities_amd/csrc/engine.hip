@@ -223,6 +223,78 @@ __device__ inline void dev_intro_select(float* d, int s, int e, int k) {
     }
 }
 
+// Wave-parallel form of the same selection: one wave per residual row. The reference's partition loop pairs the i-th element
+// > pivot from the left with the i-th element < pivot from the right and swaps them while they have not crossed; that final
+// arrangement (and the pivot's resting place) is a pure function of the row, so it is computed with ballots / prefix counts
+// instead of a cell-by-cell scan, and the result is bit-identical to the sequential routine above. `idx` is scratch of n ints.
+__device__ __forceinline__ void wave_sync_lds() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+__device__ inline void wave_intro_select(float* d, int* idx, int n, int k, int lane) {
+    int s = 0, e = n - 1;
+    int prev = e - s + 1, tries = 0; bool quick = true;
+    for (;;) {
+        if (s >= e) break;
+        if (e - s <= 5) {
+            if (lane == 0) { float t; for (int i = s + 1; i <= e; i++) for (int j = i; j > s && d[j - 1] > d[j]; j--) { t = d[j - 1]; d[j - 1] = d[j]; d[j] = t; } }
+            break;
+        }
+        if (quick && tries++ == 5) { const int len = e - s + 1; if (len * 2 > prev) quick = false; prev = len; tries = 0; }
+        int pi;
+        if (quick) pi = sel_pivot_ends(d, s, e);                       // three uniform reads
+        else {
+            int tmp = 0;
+            if (lane == 0) tmp = sel_median_of_medians(d, s, e);       // rare fallback: one lane, the reference's in-place group medians
+            wave_sync_lds();
+            pi = __shfl(tmp, 0, 64);
+        }
+        const float piv = d[pi];
+        wave_sync_lds();
+        if (pi != s && lane == 0) { d[pi] = d[s]; d[s] = piv; }
+        wave_sync_lds();
+        // lane l owns the contiguous chunk [b0, b1) of (s, e]
+        const int L = e - s;                                           // elements besides the pivot
+        const int c = (L + 63) / 64;
+        const int b0 = s + 1 + lane * c, b1 = min(b0 + c, e + 1);
+        int ng = 0, nl = 0;
+        for (int p = b0; p < b1; p++) { const float v = d[p]; ng += v > piv; nl += v < piv; }
+        // exclusive prefix of ng over lanes (left to right) and of nl over lanes (right to left)
+        int pg = ng, pl = nl;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const int tg = __shfl_up(pg, off, 64); if (lane >= off) pg += tg;
+            const int tl = __shfl_down(pl, off, 64); if (lane + off < 64) pl += tl;
+        }
+        const int nG = __shfl(pg, 63, 64), nLt = __shfl(pl, 0, 64);
+        pg -= ng; pl -= nl;
+        // idx[i] = position of the i-th '>' from the left; idx[L-1-i] = position of the i-th '<' from the right (nG + nLt <= L)
+        { int rg = pg; for (int p = b0; p < b1; p++) if (d[p] > piv) idx[rg++] = p; }
+        { int rl = pl; for (int p = b1 - 1; p >= b0; p--) if (d[p] < piv) idx[L - 1 - (rl++)] = p; }
+        wave_sync_lds();
+        // pair i is swapped iff its two members have not crossed; pairs are disjoint, so one lane per pair is race-free
+        int t = 0;
+        for (int i = lane, m = min(nG, nLt); i < m; i += 64) {
+            const int a = idx[i], b = idx[L - 1 - i];
+            if (a < b) { const float va = d[a]; d[a] = d[b]; d[b] = va; t++; }
+        }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) t += __shfl_xor(t, off, 64);
+        wave_sync_lds();
+        // where the reference's scan pointers end up, and where the pivot comes to rest (jly_sorting.hpp:282-303)
+        const int hi0 = t > 0 ? idx[L - 1 - (t - 1)] : e;
+        int lo1 = hi0; bool lo_is_greater;
+        if (t < nG && idx[t] < hi0) { lo1 = idx[t]; lo_is_greater = true; }
+        else lo_is_greater = t > 0 ? true : !(d[e] < piv);            // t == 0: d[e] is untouched; '<' means the pivot swaps with it
+        const int sp = lo_is_greater ? lo1 - 1 : lo1;
+        if (lane == 0) { d[s] = d[sp]; d[sp] = piv; }
+        wave_sync_lds();
+        if (sp < k) s = sp + 1; else if (sp > k) e = sp - 1; else break;
+    }
+    wave_sync_lds();
+}
+
 template <int BLOCK>
 struct TileShm {
     float cube[TC][4];        // x, y, z, w
@@ -312,7 +384,8 @@ __device__ __forceinline__ void sweep_tile(const DevTables& T, TileShm<BLOCK>& s
             }
         }
         __syncthreads();
-        if (tid < TC) dev_intro_select(rbuf + tid * Nd, 0, Nd - 1, T.inlierNum - 1);
+        for (int j = tid >> 6; j < TC; j += BLOCK / 64)
+            wave_intro_select(rbuf + j * Nd, reinterpret_cast<int*>(rbuf + TC * Nd) + j * Nd, Nd, T.inlierNum - 1, tid & 63);
         __syncthreads();
         if (tid < 2 * TC) {
             const int j = tid & (TC - 1);

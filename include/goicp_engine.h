@@ -75,8 +75,11 @@ typedef struct goicp_engine_desc {
     float   regularizationNeighbors;   /* must be 0 (direct-neighbour penalty is out of scope) */
     float   regularizationFPFH;
     int32_t device_id;
-    /* 1: ub/lb summed in the reference's order (float, sequential over points; bit-exact for untrimmed
-     *    runs; used when Nd <= 1024, else falls back to 0).  0: fp64 tree reduction (order-free; within n*eps of the reference). */
+    /* 1: reference-order arithmetic for clouds of Nd <= 1024 points (every cavity cloud): float sums taken sequentially over
+     *    the point index, and for trimmed runs the reference's own selection (intro_select, same swap sequence) on the
+     *    device -- (ub, lb), InnerBnB results and whole registrations are bit-identical to the reference. Larger clouds fall
+     *    back to 0.  0: order-free fp64 sums and an exact histogram selection (same inlier multiset; bounds within n*eps of
+     *    the reference, so a search may settle on a different epsilon-optimal node). */
     int32_t parity_mode;
 } goicp_engine_desc;
 

@@ -329,3 +329,21 @@ def test_neighbour_weights_on_device_match_oracle():
     g = goicp_amd.GoICP(v); g.set_clouds(P["t"], P["s"]); g.build_dt(); g.initialize()
     assert np.array_equal(g.weights(), o.weights())
     g.close()
+
+
+def test_c3_headline_pair_matches_reference_known_answer():
+    """BASELINE configs[2] itself (5 000 points, 300^3 DT, trimFraction 0.1; the bench.py pair). Nd > 1024, so the sums are fp64
+    and only tolerance is promised; tests/golden/c3_reference.json holds the compiled reference's result on the same inputs
+    (10.4 s Register + 19.9 s BuildDT on the build container): R, t within 1e-5, error within 1e-5 relative, same number of
+    translation-queue pops."""
+    import json
+    from goicp_amd.synth import synth_pair
+    G = json.load(open(os.path.join(GOLDEN, "c3_reference.json")))
+    P = synth_pair(5000, seed=20260101, theta_range=(2.2, 3.1))
+    v = goicp_amd.cfg_vector(MSEThresh=0.001, trimFraction=0.1, regularization=0.0, regularizationFPFH=0.0, cfpfh=0, ponderation=0, norm=2, distTransSize=300)
+    g = goicp_amd.GoICP(v); g.set_clouds(P["t"], P["s"]); g.build_dt()
+    out = g.register()
+    assert abs(float(out["error"]) - G["error"]) <= 1e-5 * G["error"]
+    assert np.abs(out["R"] - np.array(G["R"])).max() < 1e-5 and np.abs(out["t"] - np.array(G["t"])).max() < 1e-5
+    assert out["stats"]["trans_pops"] == G["pops"]
+    g.close()
