@@ -319,18 +319,21 @@ struct TileShm {
 // Evaluate the TC cubes whose descriptors sit in sh.cube[] against the PPT points each lane holds in
 // registers. Results: sh.ub[], sh.lb[] (geometric part only; the penalty part is added by the caller).
 // Restates reference jly_goicp.cpp:343-415.
-template <int BLOCK, int PPT, bool OCT>
+// NT = cubes of the tile (TC everywhere today; 4-cube tiles with two 512-lane workgroups per CU measured no faster)
+template <int BLOCK, int PPT, bool OCT, int NT>
 __device__ __forceinline__ void sweep_tile(const DevTables& T, TileShm<BLOCK>& sh, const float (&px)[PPT], const float (&py)[PPT],
                                            const float (&pz)[PPT], const float (&pw)[PPT], const float (&prho)[PPT], bool use_rho,
                                            float* rbuf /* LDS, exact mode only */) {
     const int tid = threadIdx.x;
     const int Nd = T.Nd;
-    float r[TC][PPT];
-    // gathers: the TC lookups of one point are issued back to back (no consumer in between), so every lane keeps
-    // TC loads in flight; lanes past Nd carry a zero point with zero weight (their residuals are never counted)
-#pragma unroll
-    for (int m = 0; m < PPT; m++) {
-        unsigned idx[TC]; float ext[TC], v[TC];
+    float r[NT][PPT];
+    // gathers: the NT lookups of one point are issued back to back (no consumer in between), so every lane keeps NT loads
+    // in flight. A lookup that leaves the grid only sets a flag bit; its extension length (jly_3ddt.cpp:1150-1187) is
+    // formed on the rare lanes that need it, after the fetch.
+    // Lanes past Nd carry a zero point with zero weight (their residuals are never counted).
+    const int S = T.S;
+    auto cells = [&](int m, unsigned (&idx)[NT]) -> unsigned {
+        unsigned oob = 0u;
         if (OCT) {
             // the 8 cubes are the 2x2x2 children of one node: child j sits at (j&1, j>>1&1, j>>2&1), so only two distinct
             // centre coordinates exist per axis and the (double) cell arithmetic is done 6 times instead of 24
@@ -342,31 +345,51 @@ __device__ __forceinline__ void sweep_tile(const DevTables& T, TileShm<BLOCK>& s
                 rz[q] = cell_of(pz[m] + sh.cen[4 * q][2], T.zMin, T.scale);
             }
 #pragma unroll
-            for (int j = 0; j < TC; j++) {
+            for (int j = 0; j < NT; j++) {
                 const int x = rx[j & 1], y = ry[j >> 1 & 1], z = rz[j >> 2 & 1];
-                idx[j] = (unsigned)((clamp_cell(z, T.S) * T.S + clamp_cell(y, T.S)) * T.S + clamp_cell(x, T.S));
-                ext[j] = dt_ext_raw(x, y, z, T.S);
+                idx[j] = (unsigned)((clamp_cell(z, S) * S + clamp_cell(y, S)) * S + clamp_cell(x, S));
+                oob |= ((((unsigned)x >= (unsigned)S) | ((unsigned)y >= (unsigned)S) | ((unsigned)z >= (unsigned)S)) ? 1u : 0u) << j;
             }
         } else if (sh.ctl[2]) {
             // the 8 cubes form a row (same y and z centre, e.g. 8 x-neighbours of a level grid): the y and z cell
             // arithmetic is shared, 10 axis computations instead of 24
             const int y = cell_of(py[m] + sh.cen[0][1], T.yMin, T.scale), z = cell_of(pz[m] + sh.cen[0][2], T.zMin, T.scale);
-            const int rowbase = (clamp_cell(z, T.S) * T.S + clamp_cell(y, T.S)) * T.S;
+            const int rowbase = (clamp_cell(z, S) * S + clamp_cell(y, S)) * S;
+            const unsigned yz_out = (((unsigned)y >= (unsigned)S) | ((unsigned)z >= (unsigned)S)) ? 1u : 0u;
 #pragma unroll
-            for (int j = 0; j < TC; j++) {
+            for (int j = 0; j < NT; j++) {
                 const int x = cell_of(px[m] + sh.cen[j][0], T.xMin, T.scale);
-                idx[j] = (unsigned)(rowbase + clamp_cell(x, T.S));
-                ext[j] = dt_ext_raw(x, y, z, T.S);
+                idx[j] = (unsigned)(rowbase + clamp_cell(x, S));
+                oob |= (yz_out | (((unsigned)x >= (unsigned)S) ? 1u : 0u)) << j;
             }
         } else {
 #pragma unroll
-            for (int j = 0; j < TC; j++) idx[j] = dt_index(T, px[m] + sh.cen[j][0], py[m] + sh.cen[j][1], pz[m] + sh.cen[j][2], ext[j]);
+            for (int j = 0; j < NT; j++) {
+                const int x = cell_of(px[m] + sh.cen[j][0], T.xMin, T.scale), y = cell_of(py[m] + sh.cen[j][1], T.yMin, T.scale), z = cell_of(pz[m] + sh.cen[j][2], T.zMin, T.scale);
+                idx[j] = (unsigned)((clamp_cell(z, S) * S + clamp_cell(y, S)) * S + clamp_cell(x, S));
+                oob |= ((((unsigned)x >= (unsigned)S) | ((unsigned)y >= (unsigned)S) | ((unsigned)z >= (unsigned)S)) ? 1u : 0u) << j;
+            }
+        }
+        return oob;
+    };
+#pragma unroll
+    for (int m = 0; m < PPT; m++) {
+        unsigned idx[NT]; float v[NT];
+        const unsigned oob = cells(m, idx);
+#pragma unroll
+        for (int j = 0; j < NT; j++) v[j] = T.dist[(T.dbg & 2) ? (idx[j] & 1023u) : idx[j]];
+        if (__any((int)oob)) {
+#pragma unroll
+            for (int j = 0; j < NT; j++) {
+                if ((oob >> j) & 1u) {
+                    float ext; (void)dt_index(T, px[m] + sh.cen[j][0], py[m] + sh.cen[j][1], pz[m] + sh.cen[j][2], ext);
+                    v[j] = dt_finish(T, v[j], ext);
+                }
+            }
         }
 #pragma unroll
-        for (int j = 0; j < TC; j++) v[j] = T.dist[(T.dbg & 2) ? (idx[j] & 1023u) : idx[j]];
-#pragma unroll
-        for (int j = 0; j < TC; j++) {
-            float d = pw[m] * dt_finish(T, v[j], ext[j]);
+        for (int j = 0; j < NT; j++) {
+            float d = pw[m] * v[j];
             if (use_rho) d -= prho[m];
             if (d < 0.f) d = 0.f;
             r[j][m] = d;
@@ -380,16 +403,16 @@ __device__ __forceinline__ void sweep_tile(const DevTables& T, TileShm<BLOCK>& s
             const int i = tid + m * BLOCK;
             if (i < Nd) {
 #pragma unroll
-                for (int j = 0; j < TC; j++) rbuf[j * Nd + i] = r[j][m];
+                for (int j = 0; j < NT; j++) rbuf[j * Nd + i] = r[j][m];
             }
         }
         __syncthreads();
-        for (int j = tid >> 6; j < TC; j += BLOCK / 64)
-            wave_intro_select(rbuf + j * Nd, reinterpret_cast<int*>(rbuf + TC * Nd) + j * Nd, Nd, T.inlierNum - 1, tid & 63);
+        for (int j = tid >> 6; j < NT; j += BLOCK / 64)
+            wave_intro_select(rbuf + j * Nd, reinterpret_cast<int*>(rbuf + NT * Nd) + j * Nd, Nd, T.inlierNum - 1, tid & 63);
         __syncthreads();
-        if (tid < 2 * TC) {
-            const int j = tid & (TC - 1);
-            const bool is_lb = tid >= TC;
+        if (tid < 2 * NT) {
+            const int j = tid & (NT - 1);
+            const bool is_lb = tid >= NT;
             const float* rr = rbuf + j * Nd;
             const float sub = is_lb ? sh.mtd[j] : 0.f;
             const bool sq = T.norm == 2, lin = T.norm == 1;
@@ -410,14 +433,14 @@ __device__ __forceinline__ void sweep_tile(const DevTables& T, TileShm<BLOCK>& s
         // turns its residuals into the two addends (d*d and max(d-mtd,0)^2, or the norm-1 forms) in parallel; 16 lanes then
         // run the 16 sequential float sums (8 ub chains, 8 lb chains), one add per element. Skipping a term (e <= 0) and
         // adding +0.0f leave the same bits because the running sums are never negative.
-        float* tub = rbuf; float* tlb = rbuf + TC * Nd;
+        float* tub = rbuf; float* tlb = rbuf + NT * Nd;
         const bool sq = T.norm == 2, lin = T.norm == 1;
 #pragma unroll
         for (int m = 0; m < PPT; m++) {
             const int i = tid + m * BLOCK;
             if (i < Nd) {
 #pragma unroll
-                for (int j = 0; j < TC; j++) {
+                for (int j = 0; j < NT; j++) {
                     const float d = r[j][m], e = d - sh.mtd[j];
                     tub[j * Nd + i] = sq ? d * d : (lin ? d : 0.f);
                     tlb[j * Nd + i] = e > 0.f ? (sq ? e * e : (lin ? e : 0.f)) : 0.f;
@@ -425,7 +448,7 @@ __device__ __forceinline__ void sweep_tile(const DevTables& T, TileShm<BLOCK>& s
             }
         }
         __syncthreads();
-        if (tid < 2 * TC) {
+        if (tid < 2 * NT) {
             const float* tt = rbuf + tid * Nd;          // lanes 0-7: ub rows, lanes 8-15: lb rows
             float acc = 0.f;
             int i = 0;
@@ -437,7 +460,7 @@ __device__ __forceinline__ void sweep_tile(const DevTables& T, TileShm<BLOCK>& s
                 for (int q = 0; q < 16; q++) acc += v[q];
             }
             for (; i < Nd; i++) acc += tt[i];
-            if (tid < TC) sh.ub[tid] = acc; else sh.lb[tid - TC] = acc;
+            if (tid < NT) sh.ub[tid] = acc; else sh.lb[tid - NT] = acc;
         }
         __syncthreads();
         return;
@@ -448,18 +471,18 @@ __device__ __forceinline__ void sweep_tile(const DevTables& T, TileShm<BLOCK>& s
     // ---- inlier threshold per cube = the inlierNum-th smallest residual, by MSB-first radix select on the float bit
     //      pattern (residuals are >= 0, so the pattern orders like the value) with LDS histograms. Replaces intro_select
     //      (reference jly_sorting.hpp:229): the selected multiset is the same, the order is not needed (order-free sums).
-    unsigned thr[TC]; int below[TC];
+    unsigned thr[NT]; int below[NT];
 #pragma unroll
-    for (int j = 0; j < TC; j++) { thr[j] = 0u; below[j] = 0; }
+    for (int j = 0; j < NT; j++) { thr[j] = 0u; below[j] = 0; }
     if (T.doTrim && !(T.dbg & 1)) {
         const int wv = tid >> 6, ln = tid & 63;
-        for (int k = tid; k < TC * 1024; k += BLOCK) (&sh.hist[0][0])[k] = 0u;
-        if (tid < TC) { sh.prefix[tid] = 0u; sh.rem[tid] = T.inlierNum - 1; sh.maxb[tid] = 0u; sh.zc[tid] = 0; sh.ncand[tid] = 0; }
+        for (int k = tid; k < NT * 1024; k += BLOCK) (&sh.hist[0][0])[k] = 0u;
+        if (tid < NT) { sh.prefix[tid] = 0u; sh.rem[tid] = T.inlierNum - 1; sh.maxb[tid] = 0u; sh.zc[tid] = 0; sh.ncand[tid] = 0; }
         if (tid == 0) sh.fallback = 0;
         __syncthreads();
         // (1) largest residual per cube: fixes the 8-octave window of the first pass
 #pragma unroll
-        for (int j = 0; j < TC; j++) {
+        for (int j = 0; j < NT; j++) {
             unsigned mx = 0u;
 #pragma unroll
             for (int m = 0; m < PPT; m++) if (tid + m * BLOCK < Nd) mx = max(mx, __float_as_uint(r[j][m]));
@@ -474,7 +497,7 @@ __device__ __forceinline__ void sweep_tile(const DevTables& T, TileShm<BLOCK>& s
         //     (frequent once a rotation-uncertainty radius is subtracted) are bit-identical and would serialise on one
         //     LDS word, so they are counted with ballots and kept out of the histogram.
 #pragma unroll
-        for (int j = 0; j < TC; j++) {
+        for (int j = 0; j < NT; j++) {
             const int base16 = max(0, (int)(sh.maxb[j] >> 16) - 1023);
             int z = 0;
 #pragma unroll
@@ -487,7 +510,7 @@ __device__ __forceinline__ void sweep_tile(const DevTables& T, TileShm<BLOCK>& s
             if (ln == 0 && z) atomicAdd(&sh.zc[j], z);
         }
         __syncthreads();
-        for (int j = wv; j < TC; j += BLOCK / 64) {     // one wave scans the 1024 bins of a cube: 16 per lane
+        for (int j = wv; j < NT; j += BLOCK / 64) {     // one wave scans the 1024 bins of a cube: 16 per lane
             unsigned c[16]; int mine = 0;
 #pragma unroll
             for (int q = 0; q < 16; q++) { c[q] = sh.hist[j][16 * ln + q]; mine += (int)c[q]; }
@@ -523,7 +546,7 @@ __device__ __forceinline__ void sweep_tile(const DevTables& T, TileShm<BLOCK>& s
         if (!sh.fallback) {
             // (3) collect the members of each threshold bin (a handful) and finish the low 16 bits inside one wave
 #pragma unroll
-            for (int j = 0; j < TC; j++) {
+            for (int j = 0; j < NT; j++) {
                 const unsigned p16 = sh.prefix[j] >> 16;
                 if (sh.ncand[j] < 0) continue;                // threshold already known (zero)
 #pragma unroll
@@ -536,7 +559,7 @@ __device__ __forceinline__ void sweep_tile(const DevTables& T, TileShm<BLOCK>& s
                 }
             }
             __syncthreads();
-            for (int j = wv; j < TC; j += BLOCK / 64) {
+            for (int j = wv; j < NT; j += BLOCK / 64) {
                 const int nc = sh.ncand[j];
                 if (nc < 0) continue;
                 const bool v0 = ln < nc, v1 = ln + 64 < nc;
@@ -555,25 +578,25 @@ __device__ __forceinline__ void sweep_tile(const DevTables& T, TileShm<BLOCK>& s
             __syncthreads();
         }
         const bool generic = sh.fallback != 0;
-        if (generic) { if (tid < TC) { sh.prefix[tid] = 0u; sh.rem[tid] = T.inlierNum - 1; } }
+        if (generic) { if (tid < NT) { sh.prefix[tid] = 0u; sh.rem[tid] = T.inlierNum - 1; } }
         // (4) generic path: four byte passes, MSB first, when the window missed or a bin was crowded
         for (int pass = generic ? 3 : -1; pass >= 0; pass--) {
             __syncthreads();
-            for (int k = tid; k < TC * 256; k += BLOCK) sh.hist[k >> 8][k & 255] = 0u;
+            for (int k = tid; k < NT * 256; k += BLOCK) sh.hist[k >> 8][k & 255] = 0u;
             __syncthreads();
             const unsigned himask = pass == 3 ? 0u : (0xFFFFFFFFu << (8 * (pass + 1)));
 #pragma unroll
             for (int m = 0; m < PPT; m++) {
                 const bool valid = tid + m * BLOCK < Nd;
 #pragma unroll
-                for (int j = 0; j < TC; j++) {
+                for (int j = 0; j < NT; j++) {
                     const unsigned bits = __float_as_uint(r[j][m]);
                     const bool take = valid && ((bits ^ sh.prefix[j]) & himask) == 0u;
                     hist_add(sh.hist[j], (bits >> (8 * pass)) & 255u, take, ln);
                 }
             }
             __syncthreads();
-            for (int j = wv; j < TC; j += BLOCK / 64) {
+            for (int j = wv; j < NT; j += BLOCK / 64) {
                 const unsigned c0 = sh.hist[j][4 * ln], c1 = sh.hist[j][4 * ln + 1], c2 = sh.hist[j][4 * ln + 2], c3 = sh.hist[j][4 * ln + 3];
                 const int mine = (int)(c0 + c1 + c2 + c3);
                 int incl = mine;
@@ -593,12 +616,12 @@ __device__ __forceinline__ void sweep_tile(const DevTables& T, TileShm<BLOCK>& s
         }
         __syncthreads();
 #pragma unroll
-        for (int j = 0; j < TC; j++) { thr[j] = sh.prefix[j]; below[j] = T.inlierNum - 1 - sh.rem[j]; }   // rem = rank among the copies of thr
+        for (int j = 0; j < NT; j++) { thr[j] = sh.prefix[j]; below[j] = T.inlierNum - 1 - sh.rem[j]; }   // rem = rank among the copies of thr
     }
     // ---- sums in fp64 (order-free), float at the end; one cube at a time to keep registers low
     const int wave = tid >> 6, lane = tid & 63;
 #pragma unroll
-    for (int j = 0; j < TC; j++) {
+    for (int j = 0; j < NT; j++) {
         // a lane's own PPT addends are summed in float (PPT <= 16 terms), everything across lanes in fp64
         float fub = 0.f, flb = 0.f;
         const float mtd = sh.mtd[j];
@@ -619,7 +642,7 @@ __device__ __forceinline__ void sweep_tile(const DevTables& T, TileShm<BLOCK>& s
     __syncthreads();
     // every lane holds thr[]/below[] (wave-uniform); lane j finishes cube j
 #pragma unroll
-    for (int j = 0; j < TC; j++) {
+    for (int j = 0; j < NT; j++) {
         if (tid == j) {
             double u = 0.0, l = 0.0;
             for (int w = 0; w < BLOCK / 64; w++) { u += sh.red[w][2 * j]; l += sh.red[w][2 * j + 1]; }
@@ -822,7 +845,9 @@ __device__ __forceinline__ void heap_pop(const HeapStore& a, int& n) {
 // ---------------------------------------------------------------------------------------------
 // k_inner_bnb
 // ---------------------------------------------------------------------------------------------
-template <int BLOCK, int PPT>
+// PEN = false compiles the penalty-term code (27-point lattice gathers) out: a purely geometric search then keeps its
+// cloud and residuals in registers without spilling.
+template <int BLOCK, int PPT, bool PEN>
 __global__ __launch_bounds__(BLOCK) void k_inner_bnb(DevTables T, const goicp_bnb_job* __restrict__ jobs, goicp_bnb_result* __restrict__ results,
                                                       HeapNode* heaps, int heap_cap, float* fpscratch, unsigned max_pops, int heap_lds_nodes, int rbuf_floats, int fp_lds) {
     __shared__ TileShm<BLOCK> sh;
@@ -865,7 +890,7 @@ __global__ __launch_bounds__(BLOCK) void k_inner_bnb(DevTables T, const goicp_bn
         HeapNode root; root.x = job.init[0]; root.y = job.init[1]; root.z = job.init[2]; root.w = job.init[3]; root.ub = 0.f; root.lb = job.init_lb;
         heap.set(0, root); hn = 1;
     }
-    const bool penalties = T.use_compat || T.use_fpfh;
+    const bool penalties = PEN && (T.use_compat || T.use_fpfh);
     const bool timing = (T.dbg & 32) && T.dbg_times && blockIdx.x == 0 && tid == 0;
     unsigned long long tph[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tlast = timing ? clock64() : 0ull;
 #define STAMP(k) do { if (timing) { const unsigned long long now_ = clock64(); tph[k] += now_ - tlast; tlast = now_; } } while (0)
@@ -907,11 +932,11 @@ __global__ __launch_bounds__(BLOCK) void k_inner_bnb(DevTables T, const goicp_bn
         }
         __syncthreads();
         STAMP(1);
-        sweep_tile<BLOCK, PPT, true>(T, sh, px, py, pz, pw, prho, use_rho, rbuf);
+        sweep_tile<BLOCK, PPT, true, TC>(T, sh, px, py, pz, pw, prho, use_rho, rbuf);
         STAMP(2);
-        if (T.use_compat) lattice_compat_oct<BLOCK, PPT>(T, sh, px, py, pz);
+        if (PEN && T.use_compat) lattice_compat_oct<BLOCK, PPT>(T, sh, px, py, pz);
         STAMP(3);
-        if (T.use_fpfh) lattice_fpfh_oct<BLOCK, PPT>(T, sh, px, py, pz, fpbuf);
+        if (PEN && T.use_fpfh) lattice_fpfh_oct<BLOCK, PPT>(T, sh, px, py, pz, fpbuf);
         STAMP(4);
         if (penalties) {
             // lanes 0-7 fold the corner terms of their child into sh.ub/sh.lb in parallel ...
@@ -960,7 +985,7 @@ __global__ __launch_bounds__(BLOCK) void k_inner_bnb(DevTables T, const goicp_bn
 // ---------------------------------------------------------------------------------------------
 // k_eval_cubes: 8 free cubes per workgroup; cloud = rotation slot prepared by k_rotate
 // ---------------------------------------------------------------------------------------------
-template <int BLOCK, int PPT>
+template <int BLOCK, int PPT, int NT>
 __global__ __launch_bounds__(BLOCK) void k_eval_cubes(DevTables T, const float4* __restrict__ rot_all /*[slots][Nd] x,y,z,weight*/, int slot0, int level0,
                                                        const int2* __restrict__ groups /* (slot, rot_level) per blockIdx.y, or null */,
                                                        const float* __restrict__ cubes, int n, float* __restrict__ ub_out, float* __restrict__ lb_out,
@@ -969,7 +994,7 @@ __global__ __launch_bounds__(BLOCK) void k_eval_cubes(DevTables T, const float4*
     extern __shared__ float rbuf[];
     const int tid = threadIdx.x;
     const int Nd = T.Nd;
-    const int base = blockIdx.x * TC;
+    const int base = blockIdx.x * NT;
     // one launch can sweep the same cube list for many (rotation, rho-level) pairs: blockIdx.y picks the pair
     int slot = slot0, rot_level = level0;
     if (groups) { const int2 g = groups[blockIdx.y]; slot = g.x; rot_level = g.y; }
@@ -986,7 +1011,7 @@ __global__ __launch_bounds__(BLOCK) void k_eval_cubes(DevTables T, const float4*
 #pragma unroll
         for (int m = 0; m < PPT; m++) { px[m] = p[m].x; py[m] = p[m].y; pz[m] = p[m].z; pw[m] = p[m].w; prho[m] = use_rho ? rh[m] : 0.f; }
     }
-    if (tid < TC) {
+    if (tid < NT) {
         const int j = tid, c = min(base + j, n - 1);          // the tail tile re-evaluates the last cube
         const float x = cubes[4 * c], y = cubes[4 * c + 1], z = cubes[4 * c + 2], w = cubes[4 * c + 3];
         sh.cube[j][0] = x; sh.cube[j][1] = y; sh.cube[j][2] = z; sh.cube[j][3] = w;
@@ -997,19 +1022,19 @@ __global__ __launch_bounds__(BLOCK) void k_eval_cubes(DevTables T, const float4*
     __syncthreads();
     if (tid == 0) {
         bool row = true;
-        for (int j = 1; j < TC; j++) row = row && sh.cen[j][1] == sh.cen[0][1] && sh.cen[j][2] == sh.cen[0][2];
+        for (int j = 1; j < NT; j++) row = row && sh.cen[j][1] == sh.cen[0][1] && sh.cen[j][2] == sh.cen[0][2];
         sh.ctl[2] = row ? 1 : 0;
     }
-    if (penalties && tid < 8 * TC) {
+    if (penalties && tid < 8 * NT) {
         const int j = tid >> 3, c = tid & 7;
         sh.lat[tid][0] = sh.cube[j][0] + (c & 1) * sh.cube[j][3];
         sh.lat[tid][1] = sh.cube[j][1] + (c >> 1 & 1) * sh.cube[j][3];
         sh.lat[tid][2] = sh.cube[j][2] + (c >> 2 & 1) * sh.cube[j][3];
     }
     __syncthreads();
-    sweep_tile<BLOCK, PPT, false>(T, sh, px, py, pz, pw, prho, use_rho, rbuf);
-    if (penalties) lattice_terms<BLOCK, PPT>(T, sh, 8 * TC, px, py, pz, fpbuf);
-    if (tid < TC && base + tid < n) {
+    sweep_tile<BLOCK, PPT, false, NT>(T, sh, px, py, pz, pw, prho, use_rho, rbuf);
+    if (penalties) lattice_terms<BLOCK, PPT>(T, sh, 8 * NT, px, py, pz, fpbuf);
+    if (tid < NT && base + tid < n) {
         const int j = tid;
         float ub = sh.ub[j], lb = sh.lb[j];
         if (penalties) {
@@ -1337,8 +1362,9 @@ extern "C" int goicp_engine_create(const goicp_engine_desc* d, goicp_engine** ou
     if (h->dyn_lds_bnb + sizeof(TileShm<1024>) + 64 > 160 * 1024) { h->err = "LDS budget exceeded"; CR(GOICP_ERR_ARG); }
     {
         // static tile state + residual rows + LDS heap can exceed the 64 KB a launch gets without asking
-#define SETATTR(B, P) do { CRH(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_inner_bnb<B, P>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->dyn_lds_bnb)); \
-                           if (h->dyn_lds) CRH(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_eval_cubes<B, P>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->dyn_lds)); } while (0)
+#define SETATTR(B, P) do { CRH(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_inner_bnb<B, P, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->dyn_lds_bnb)); \
+                           CRH(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_inner_bnb<B, P, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->dyn_lds_bnb)); \
+                           if (h->dyn_lds) CRH(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_eval_cubes<B, P, TC>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->dyn_lds)); } while (0)
         DISPATCH_GEOM(h, SETATTR);
 #undef SETATTR
     }
@@ -1395,7 +1421,7 @@ static int launch_eval(goicp_engine* h, int slot, int rot_level, const int2* gro
     const int tiles = (n + TC - 1) / TC;
     int rc = ensure_fpscratch(h, (size_t)tiles * ngroups);
     if (rc != GOICP_OK) return rc;
-#define CALL(B, P) hipLaunchKernelGGL((k_eval_cubes<B, P>), dim3(tiles, ngroups), dim3(B), h->dyn_lds, h->stream, h->T, h->d_rot, slot, rot_level, groups_dev, (const float*)cubes_dev, n, (float*)ub_dev, (float*)lb_dev, h->d_fpscratch)
+#define CALL(B, P) hipLaunchKernelGGL((k_eval_cubes<B, P, TC>), dim3(tiles, ngroups), dim3(B), h->dyn_lds, h->stream, h->T, h->d_rot, slot, rot_level, groups_dev, (const float*)cubes_dev, n, (float*)ub_dev, (float*)lb_dev, h->d_fpscratch)
     DISPATCH_GEOM(h, CALL);
 #undef CALL
     HIPCHK(h, hipGetLastError());
@@ -1489,7 +1515,8 @@ static int run_bnb(goicp_engine* h, const goicp_bnb_job* jobs, int njobs, goicp_
     if (rc != GOICP_OK) return rc;
     HIPCHK(h, hipMemcpyAsync(h->d_jobs, jobs, (size_t)njobs * sizeof(goicp_bnb_job), hipMemcpyHostToDevice, h->stream));
     HIPCHK(h, hipEventRecord(h->ev0, h->stream));
-#define CALL(B, P) hipLaunchKernelGGL((k_inner_bnb<B, P>), dim3(njobs), dim3(B), h->dyn_lds_bnb, h->stream, h->T, h->d_jobs, h->d_results, heaps, cap, h->d_fpscratch, h->max_pops, h->heap_lds_nodes, h->rbuf_floats, h->fp_lds)
+#define CALL(B, P) do { if (h->T.use_compat || h->T.use_fpfh) hipLaunchKernelGGL((k_inner_bnb<B, P, true>), dim3(njobs), dim3(B), h->dyn_lds_bnb, h->stream, h->T, h->d_jobs, h->d_results, heaps, cap, h->d_fpscratch, h->max_pops, h->heap_lds_nodes, h->rbuf_floats, h->fp_lds); \
+                        else hipLaunchKernelGGL((k_inner_bnb<B, P, false>), dim3(njobs), dim3(B), h->dyn_lds_bnb, h->stream, h->T, h->d_jobs, h->d_results, heaps, cap, h->d_fpscratch, h->max_pops, h->heap_lds_nodes, h->rbuf_floats, h->fp_lds); } while (0)
     DISPATCH_GEOM(h, CALL);
 #undef CALL
     HIPCHK(h, hipGetLastError());

@@ -222,6 +222,48 @@ def test_synthetic_cloud_against_oracle(n, S, trim):
     e.close()
 
 
+@pytest.mark.parametrize("kind", ["outside_grid", "duplicates", "wide_range", "norm1_untrimmed"])
+def test_wave_sweep_edge_cases_against_oracle(kind):
+    """The one-wave-per-cube sweep (clouds of 1025..5120 points without penalty terms): cubes that push most points out
+    of the DT grid (extension path), clouds whose residuals crowd one histogram bin or span more than the 8-octave window
+    (generic byte passes), and the norm-1 untrimmed sums -- each against the oracle's cube evaluation."""
+    n, S = 2000, 60
+    P = synth_pair(n, seed=77)
+    s = P["s"].copy(); trim = 0.1; norm = 2
+    rng = np.random.default_rng(5)
+    if kind == "duplicates":
+        s[:] = s[0]                                   # every residual of a cube is the same value
+    elif kind == "wide_range":
+        s = (P["t"][rng.integers(0, len(P["t"]), n)] + rng.normal(0, 1e-4, (n, 3))).astype(np.float32)
+        s[: n // 20] += np.float32(0.9)               # a few residuals ~1e3 x the rest: the threshold falls below the window
+    elif kind == "norm1_untrimmed":
+        trim = 0.0; norm = 1
+    P = dict(P); P["s"] = s
+    v, _ = cfg_vector(distTransSize=S, trimFraction=trim, regularization=0.0, ponderation=0, MSEThresh=0.001, norm=norm)
+    o = oracle_for(P, v); o.initialize()
+    dist, near3, cc, _ = o.dt_dump()
+    e = goicp_amd.Engine(S=S, geom4=(o.geom[0], o.geom[2], o.geom[4], o.geom[6]), dist=dist, data_xyz=P["s"], weights=o.weights(),
+                         maxrotdis=o.maxrotdis(), model_xyz=P["t"], inlier_num=o.inlier_num(), do_trim=trim >= 0.001, norm=norm, parity_mode=0)
+    R = np.eye(3, dtype=np.float32) if kind == "wide_range" else o.axis_angle(np.float32([0.3, -1.1, 0.7]))
+    o.rotate(R); e.set_rotation(0, R)
+    cubes = []
+    for L in (0, 2, 4, 7):
+        w = np.float32(1.0 / 2 ** L)
+        for a in rng.uniform(-0.5, 0.5 - float(w), (20, 3)).astype(np.float32):
+            cubes.append([a[0], a[1], a[2], w])
+    if kind == "wide_range":
+        cubes += [[np.float32(-1e-3), np.float32(-1e-3), np.float32(-1e-3), np.float32(2e-3)]] * 3
+    cubes = np.array(cubes, np.float32)
+    if kind == "outside_grid":
+        cubes[::2, :3] += np.float32([2.5, -1.5, 0.75])
+    for lvl in (-1, 0, 3):
+        ub, lb = e.eval_cubes(0, lvl, cubes)
+        oub, olb = o.eval_cubes(lvl, cubes)
+        assert close(ub, oub, False, n) and close(lb, olb, False, n), (kind, lvl, np.abs(ub - oub).max(), np.abs(lb - olb).max())
+        assert np.all(lb <= ub * (1 + 1e-6) + 1e-12)
+    e.close()
+
+
 def test_multi_group_launch_equals_single_launches():
     H = load_hotpath("pair1_default"); P = load_clouds("pair1")
     import torch
