@@ -223,10 +223,10 @@ def test_synthetic_cloud_against_oracle(n, S, trim):
 
 
 @pytest.mark.parametrize("kind", ["outside_grid", "duplicates", "wide_range", "norm1_untrimmed"])
-def test_wave_sweep_edge_cases_against_oracle(kind):
-    """The one-wave-per-cube sweep (clouds of 1025..5120 points without penalty terms): cubes that push most points out
-    of the DT grid (extension path), clouds whose residuals crowd one histogram bin or span more than the 8-octave window
-    (generic byte passes), and the norm-1 untrimmed sums -- each against the oracle's cube evaluation."""
+def test_large_cloud_sweep_edge_cases_against_oracle(kind):
+    """The histogram-select sweep used above 1024 points (fp64 sums): cubes that push most points out of the DT grid
+    (extension path), clouds whose residuals crowd one histogram bin or span more than the 8-octave window (generic byte
+    passes), and the norm-1 untrimmed sums -- each against the oracle's cube evaluation."""
     n, S = 2000, 60
     P = synth_pair(n, seed=77)
     s = P["s"].copy(); trim = 0.1; norm = 2
