@@ -55,6 +55,9 @@ struct DevTables {
     int Nd, Nm, inlierNum, doTrim, norm, b0, b1;
     float reg, regFPFH;
     int use_compat, use_fpfh, exact;
+    float4* srot;            // streaming path (Nd > 8192): per-workgroup rotated cloud [NdP]
+    float* srows;            // streaming path, trimmed runs: per-workgroup residual rows [TC][NdP]
+    int NdP;                 // row pitch of the two above
     int dbg;                 // GOICP_DBG ablation bits (diagnosis only; results are wrong when set)
     unsigned long long* dbg_times;   // [8] per-phase cycle sums of job 0, lane 0 (GOICP_DBG & 32)
 };
@@ -843,11 +846,296 @@ __device__ __forceinline__ void heap_pop(const HeapStore& a, int& n) {
 }
 
 // ---------------------------------------------------------------------------------------------
+// sweep_stream: the tile sweep for clouds that do not fit a workgroup's registers (Nd > 8192; geometric error only, fp64 sums).
+// The workgroup walks the rotated cloud in chunks of 1024 points (coalesced float4 reads), 8 gathers per lane and chunk.
+// Untrimmed runs accumulate the two sums on the fly. Trimmed runs park the residuals in a per-workgroup row buffer in HBM
+// (8 x Nd floats; 288 GB make that affordable) and find the exact inlier threshold with the same histogram select as
+// sweep_tile: one pass over the rows for the 1024-bin window, one pass that sums everything below the threshold bin and
+// collects the bin's members, in-wave bisection of the low 16 bits; the generic byte passes re-read the rows.
+// ---------------------------------------------------------------------------------------------
+template <bool OCT>
+__device__ __forceinline__ void sweep_stream(const DevTables& T, TileShm<1024>& sh, const float4* __restrict__ rot, const float* __restrict__ rho_row,
+                                             float* __restrict__ rows, int NdP) {
+    constexpr int BLOCK = 1024;
+    const int tid = threadIdx.x, wv = tid >> 6, ln = tid & 63;
+    const int Nd = T.Nd, S = T.S;
+    const bool row_mode = !OCT && sh.ctl[2];
+    const bool sq = T.norm == 2, lin = T.norm == 1;
+    const bool trim = T.doTrim != 0;
+    double su[TC], sl[TC]; unsigned mx[TC];
+#pragma unroll
+    for (int j = 0; j < TC; j++) { su[j] = 0.0; sl[j] = 0.0; mx[j] = 0u; }
+    auto add_terms = [&](int j, float d) {           // the two addends of one residual (jly_goicp.cpp:393-415), into lane-local fp64
+        const float e = d - sh.mtd[j];
+        const float tu = sq ? d * d : (lin ? d : 0.f);
+        const float tl = sq ? e * e : (lin ? e : 0.f);
+        su[j] += (double)tu;
+        if (e > 0.f) sl[j] += (double)tl;
+    };
+    for (int b = 0; b < Nd; b += BLOCK) {
+        const int i = b + tid;
+        const bool valid = i < Nd;
+        const float4 p = rot[valid ? i : Nd - 1];
+        const float rh = rho_row ? rho_row[valid ? i : Nd - 1] : 0.f;
+        unsigned idx[TC]; unsigned oob = 0u;
+        if (OCT) {
+            int rx[2], ry[2], rz[2];
+#pragma unroll
+            for (int q = 0; q < 2; q++) {
+                rx[q] = cell_of(p.x + sh.cen[q][0], T.xMin, T.scale);
+                ry[q] = cell_of(p.y + sh.cen[2 * q][1], T.yMin, T.scale);
+                rz[q] = cell_of(p.z + sh.cen[4 * q][2], T.zMin, T.scale);
+            }
+#pragma unroll
+            for (int j = 0; j < TC; j++) {
+                const int x = rx[j & 1], y = ry[j >> 1 & 1], z = rz[j >> 2 & 1];
+                idx[j] = (unsigned)((clamp_cell(z, S) * S + clamp_cell(y, S)) * S + clamp_cell(x, S));
+                oob |= ((((unsigned)x >= (unsigned)S) | ((unsigned)y >= (unsigned)S) | ((unsigned)z >= (unsigned)S)) ? 1u : 0u) << j;
+            }
+        } else if (row_mode) {
+            const int y = cell_of(p.y + sh.cen[0][1], T.yMin, T.scale), z = cell_of(p.z + sh.cen[0][2], T.zMin, T.scale);
+            const int rowbase = (clamp_cell(z, S) * S + clamp_cell(y, S)) * S;
+            const unsigned yz_out = (((unsigned)y >= (unsigned)S) | ((unsigned)z >= (unsigned)S)) ? 1u : 0u;
+#pragma unroll
+            for (int j = 0; j < TC; j++) {
+                const int x = cell_of(p.x + sh.cen[j][0], T.xMin, T.scale);
+                idx[j] = (unsigned)(rowbase + clamp_cell(x, S));
+                oob |= (yz_out | (((unsigned)x >= (unsigned)S) ? 1u : 0u)) << j;
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < TC; j++) {
+                const int x = cell_of(p.x + sh.cen[j][0], T.xMin, T.scale), y = cell_of(p.y + sh.cen[j][1], T.yMin, T.scale), z = cell_of(p.z + sh.cen[j][2], T.zMin, T.scale);
+                idx[j] = (unsigned)((clamp_cell(z, S) * S + clamp_cell(y, S)) * S + clamp_cell(x, S));
+                oob |= ((((unsigned)x >= (unsigned)S) | ((unsigned)y >= (unsigned)S) | ((unsigned)z >= (unsigned)S)) ? 1u : 0u) << j;
+            }
+        }
+        float v[TC];
+#pragma unroll
+        for (int j = 0; j < TC; j++) v[j] = T.dist[idx[j]];
+        if (__any((int)oob)) {
+#pragma unroll
+            for (int j = 0; j < TC; j++) {
+                if ((oob >> j) & 1u) {
+                    float ext; (void)dt_index(T, p.x + sh.cen[j][0], p.y + sh.cen[j][1], p.z + sh.cen[j][2], ext);
+                    v[j] = dt_finish(T, v[j], ext);
+                }
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < TC; j++) {
+            float d = p.w * v[j];
+            if (rho_row) d -= rh;
+            if (d < 0.f) d = 0.f;
+            if (valid) {
+                if (trim) { rows[(size_t)j * NdP + i] = d; mx[j] = max(mx[j], __float_as_uint(d)); }
+                else add_terms(j, d);
+            }
+        }
+    }
+    unsigned thr[TC]; int below[TC];
+#pragma unroll
+    for (int j = 0; j < TC; j++) { thr[j] = 0xFFFFFFFFu; below[j] = 0; }
+    if (trim) {
+        for (int k = tid; k < TC * 1024; k += BLOCK) (&sh.hist[0][0])[k] = 0u;
+        if (tid < TC) { sh.prefix[tid] = 0u; sh.rem[tid] = T.inlierNum - 1; sh.maxb[tid] = 0u; sh.zc[tid] = 0; sh.ncand[tid] = 0; }
+        if (tid == 0) sh.fallback = 0;
+        __syncthreads();                                   // also orders the row stores before the row loads below
+#pragma unroll
+        for (int j = 0; j < TC; j++) {
+            unsigned m = mx[j];
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) m = max(m, (unsigned)__shfl_down((int)m, off, 64));
+            if (ln == 0) atomicMax(&sh.maxb[j], m);
+        }
+        __syncthreads();
+        // pass 1 over the rows: 1024-bin window below each cube's maximum, exact zeros counted with ballots
+        {
+            int base16[TC], z[TC];
+#pragma unroll
+            for (int j = 0; j < TC; j++) { base16[j] = max(0, (int)(sh.maxb[j] >> 16) - 1023); z[j] = 0; }
+            for (int b = 0; b < Nd; b += BLOCK) {
+                const int i = b + tid;
+                const bool valid = i < Nd;
+                unsigned bits[TC];
+#pragma unroll
+                for (int j = 0; j < TC; j++) bits[j] = valid ? __float_as_uint(rows[(size_t)j * NdP + i]) : 0u;
+#pragma unroll
+                for (int j = 0; j < TC; j++) {
+                    z[j] += __popcll(__ballot(valid && bits[j] == 0u));
+                    if (valid && bits[j] != 0u) atomicAdd(&sh.hist[j][max(0, (int)(bits[j] >> 16) - base16[j])], 1u);
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < TC; j++) if (ln == 0 && z[j]) atomicAdd(&sh.zc[j], z[j]);
+        }
+        __syncthreads();
+        for (int j = wv; j < TC; j += BLOCK / 64) {          // one wave scans the 1024 bins of a cube: 16 per lane
+            unsigned c[16]; int mine = 0;
+#pragma unroll
+            for (int q = 0; q < 16; q++) { c[q] = sh.hist[j][16 * ln + q]; mine += (int)c[q]; }
+            int incl = mine;
+#pragma unroll
+            for (int off = 1; off < 64; off <<= 1) { const int t = __shfl_up(incl, off, 64); if (ln >= off) incl += t; }
+            const int zc = sh.zc[j];
+            const int rank = sh.rem[j];
+            if (rank < zc) {                                  // the threshold is one of the zeros
+                if (ln == 0) { sh.prefix[j] = 0u; sh.rem[j] = rank; sh.ncand[j] = -1; }
+                continue;
+            }
+            const int rem = rank - zc;
+            const unsigned long long over = __ballot(incl > rem);
+            const int owner = over ? __ffsll((long long)over) - 1 : 63;
+            if (ln == owner) {
+                int rr = rem - (incl - mine);
+                int bq = 0;
+#pragma unroll
+                for (int q = 0; q < 15; q++) { if (bq == q && rr >= (int)c[q]) { rr -= (int)c[q]; bq = q + 1; } }
+                unsigned cb = c[0];
+#pragma unroll
+                for (int q = 1; q < 16; q++) if (bq == q) cb = c[q];
+                const int bin = 16 * ln + bq;
+                const int base16 = max(0, (int)(sh.maxb[j] >> 16) - 1023);
+                if ((bin == 0 && base16 > 0) || cb > CAND_CAP) sh.fallback = 1;
+                sh.prefix[j] = (unsigned)(base16 + bin) << 16;
+                sh.rem[j] = rr;
+            }
+        }
+        __syncthreads();
+        const bool generic = sh.fallback != 0;
+        if (!generic) {
+            // pass 2 over the rows: everything below the threshold bin is summed, the bin's members are collected
+            unsigned p16[TC]; bool known[TC];
+#pragma unroll
+            for (int j = 0; j < TC; j++) { p16[j] = sh.prefix[j] >> 16; known[j] = sh.ncand[j] < 0; }
+            for (int b = 0; b < Nd; b += BLOCK) {
+                const int i = b + tid;
+                if (i < Nd) {
+                    float d[TC];
+#pragma unroll
+                    for (int j = 0; j < TC; j++) d[j] = rows[(size_t)j * NdP + i];
+#pragma unroll
+                    for (int j = 0; j < TC; j++) {
+                        const unsigned bits = __float_as_uint(d[j]);
+                        if (bits == 0u) continue;               // zeros add nothing to either sum
+                        const unsigned b16 = bits >> 16;
+                        if (b16 < p16[j]) add_terms(j, d[j]);
+                        else if (b16 == p16[j] && !known[j]) { const int pos = atomicAdd(&sh.ncand[j], 1); if (pos < CAND_CAP) sh.cand[j][pos] = bits; }
+                    }
+                }
+            }
+            __syncthreads();
+            for (int j = wv; j < TC; j += BLOCK / 64) {
+                const int nc = sh.ncand[j];
+                if (nc < 0) continue;
+                const bool v0 = ln < nc, v1 = ln + 64 < nc;
+                const unsigned c0 = v0 ? sh.cand[j][ln] : 0u, c1 = v1 ? sh.cand[j][ln + 64] : 0u;
+                const int rem = sh.rem[j];
+                unsigned pre = sh.prefix[j];
+#pragma unroll
+                for (int bb = 15; bb >= 0; bb--) {
+                    const unsigned cnd = pre | (1u << bb);
+                    const int cnt = __popcll(__ballot(v0 && c0 < cnd)) + __popcll(__ballot(v1 && c1 < cnd));
+                    if (cnt <= rem) pre = cnd;
+                }
+                const int less = __popcll(__ballot(v0 && c0 < pre)) + __popcll(__ballot(v1 && c1 < pre));
+                if (ln == 0) { sh.prefix[j] = pre; sh.rem[j] = rem - less; }
+                // the bin members below the threshold join this wave's partial sums of cube j
+#pragma unroll
+                for (int jj = 0; jj < TC; jj++) {
+                    if (jj == j) {
+                        if (v0 && c0 < pre) add_terms(jj, __uint_as_float(c0));
+                        if (v1 && c1 < pre) add_terms(jj, __uint_as_float(c1));
+                    }
+                }
+            }
+            __syncthreads();
+        } else {
+            if (tid < TC) { sh.prefix[tid] = 0u; sh.rem[tid] = T.inlierNum - 1; }
+            for (int pass = 3; pass >= 0; pass--) {
+                __syncthreads();
+                for (int k = tid; k < TC * 256; k += BLOCK) sh.hist[k >> 8][k & 255] = 0u;
+                __syncthreads();
+                const unsigned himask = pass == 3 ? 0u : (0xFFFFFFFFu << (8 * (pass + 1)));
+                unsigned pf[TC];
+#pragma unroll
+                for (int j = 0; j < TC; j++) pf[j] = sh.prefix[j];
+                for (int b = 0; b < Nd; b += BLOCK) {
+                    const int i = b + tid;
+                    const bool valid = i < Nd;
+#pragma unroll
+                    for (int j = 0; j < TC; j++) {
+                        const unsigned bits = valid ? __float_as_uint(rows[(size_t)j * NdP + i]) : 0u;
+                        const bool take = valid && ((bits ^ pf[j]) & himask) == 0u;
+                        hist_add(sh.hist[j], (bits >> (8 * pass)) & 255u, take, ln);
+                    }
+                }
+                __syncthreads();
+                for (int j = wv; j < TC; j += BLOCK / 64) {
+                    const unsigned c0 = sh.hist[j][4 * ln], c1 = sh.hist[j][4 * ln + 1], c2 = sh.hist[j][4 * ln + 2], c3 = sh.hist[j][4 * ln + 3];
+                    const int mine = (int)(c0 + c1 + c2 + c3);
+                    int incl = mine;
+#pragma unroll
+                    for (int off = 1; off < 64; off <<= 1) { const int t = __shfl_up(incl, off, 64); if (ln >= off) incl += t; }
+                    const int rem = sh.rem[j];
+                    const unsigned long long over = __ballot(incl > rem);
+                    const int owner = over ? __ffsll((long long)over) - 1 : 63;
+                    if (ln == owner) {
+                        int rr = rem - (incl - mine);
+                        unsigned dgt = 4u * ln;
+                        if (rr >= (int)c0) { rr -= (int)c0; dgt++; if (rr >= (int)c1) { rr -= (int)c1; dgt++; if (rr >= (int)c2) { rr -= (int)c2; dgt++; } } }
+                        sh.prefix[j] |= dgt << (8 * pass);
+                        sh.rem[j] = rr;
+                    }
+                }
+            }
+            __syncthreads();
+            unsigned tj[TC];
+#pragma unroll
+            for (int j = 0; j < TC; j++) tj[j] = sh.prefix[j];
+            for (int b = 0; b < Nd; b += BLOCK) {
+                const int i = b + tid;
+                if (i < Nd) {
+#pragma unroll
+                    for (int j = 0; j < TC; j++) { const float d = rows[(size_t)j * NdP + i]; if (__float_as_uint(d) < tj[j]) add_terms(j, d); }
+                }
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < TC; j++) { thr[j] = sh.prefix[j]; below[j] = T.inlierNum - 1 - sh.rem[j]; }
+    }
+#pragma unroll
+    for (int j = 0; j < TC; j++) {
+        const double u = wave_sum(su[j]), l = wave_sum(sl[j]);
+        if (ln == 0) { sh.red[wv][2 * j] = u; sh.red[wv][2 * j + 1] = l; }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < TC; j++) {
+        if (tid == j) {
+            double u = 0.0, l = 0.0;
+            for (int w = 0; w < BLOCK / 64; w++) { u += sh.red[w][2 * j]; l += sh.red[w][2 * j + 1]; }
+            if (trim) {
+                const float d = __uint_as_float(thr[j]);
+                const float e = d - sh.mtd[j];
+                const double n = (double)(T.inlierNum - below[j]);
+                if (sq) { u += n * (double)(d * d); if (e > 0.f) l += n * (double)(e * e); }
+                else if (lin) { u += n * (double)d; if (e > 0.f) l += n * (double)e; }
+            }
+            sh.ub[j] = (float)u; sh.lb[j] = (float)l;
+        }
+    }
+    __syncthreads();
+}
+
+// ---------------------------------------------------------------------------------------------
 // k_inner_bnb
 // ---------------------------------------------------------------------------------------------
 // PEN = false compiles the penalty-term code (27-point lattice gathers) out: a purely geometric search then keeps its
 // cloud and residuals in registers without spilling.
-template <int BLOCK, int PPT, bool PEN>
+// STREAM = true (BLOCK 1024, PPT 1, PEN false): clouds above 8192 points; the rotated cloud lives in the workgroup's slice of
+// T.srot and every pop streams it through sweep_stream instead of holding it in registers.
+template <int BLOCK, int PPT, bool PEN, bool STREAM = false>
 __global__ __launch_bounds__(BLOCK) void k_inner_bnb(DevTables T, const goicp_bnb_job* __restrict__ jobs, goicp_bnb_result* __restrict__ results,
                                                       HeapNode* heaps, int heap_cap, float* fpscratch, unsigned max_pops, int heap_lds_nodes, int rbuf_floats, int fp_lds) {
     __shared__ TileShm<BLOCK> sh;
@@ -864,7 +1152,24 @@ __global__ __launch_bounds__(BLOCK) void k_inner_bnb(DevTables T, const goicp_bn
     // K5 fused: pDataTemp = R*p, float, left to right (reference jly_goicp.cpp:750-756)
     float px[PPT], py[PPT], pz[PPT], pw[PPT], prho[PPT];
     const bool use_rho = job.rot_level >= 0;
-    {
+    float4* srot = nullptr; float* srows = nullptr; const float* srho = nullptr;
+    if constexpr (STREAM) {
+        srot = T.srot + (size_t)blockIdx.x * T.NdP;
+        srows = T.srows ? T.srows + (size_t)blockIdx.x * TC * T.NdP : nullptr;
+        srho = use_rho ? T.maxRotDis + (size_t)job.rot_level * Nd : nullptr;
+        for (int i = tid; i < Nd; i += BLOCK) {
+            const float x = T.dxyz[3 * i], y = T.dxyz[3 * i + 1], z = T.dxyz[3 * i + 2];
+            float4 p;
+            p.x = job.R[0] * x + job.R[1] * y + job.R[2] * z;
+            p.y = job.R[3] * x + job.R[4] * y + job.R[5] * z;
+            p.z = job.R[6] * x + job.R[7] * y + job.R[8] * z;
+            p.w = T.weights[i];
+            srot[i] = p;
+        }
+#pragma unroll
+        for (int m = 0; m < PPT; m++) { px[m] = py[m] = pz[m] = pw[m] = prho[m] = 0.f; }
+        __syncthreads();
+    } else {
         float x[PPT], y[PPT], z[PPT], rh[PPT];
         const float* rho_row = T.maxRotDis + (size_t)(use_rho ? job.rot_level : 0) * Nd;
 #pragma unroll
@@ -932,7 +1237,8 @@ __global__ __launch_bounds__(BLOCK) void k_inner_bnb(DevTables T, const goicp_bn
         }
         __syncthreads();
         STAMP(1);
-        sweep_tile<BLOCK, PPT, true, TC>(T, sh, px, py, pz, pw, prho, use_rho, rbuf);
+        if constexpr (STREAM) sweep_stream<true>(T, sh, srot, srho, srows, T.NdP);
+        else sweep_tile<BLOCK, PPT, true, TC>(T, sh, px, py, pz, pw, prho, use_rho, rbuf);
         STAMP(2);
         if (PEN && T.use_compat) lattice_compat_oct<BLOCK, PPT>(T, sh, px, py, pz);
         STAMP(3);
@@ -979,6 +1285,43 @@ __global__ __launch_bounds__(BLOCK) void k_inner_bnb(DevTables T, const goicp_bn
         r.optErrorT = optErrorT; r.node[0] = bx; r.node[1] = by; r.node[2] = bz; r.node[3] = bw;
         r.found = found; r.status = status; r.pops = pops; r.cube_evals = cubes;
         results[blockIdx.x] = r;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// k_eval_cubes_stream: k_eval_cubes for clouds above 8192 points. Persistent workgroups walk the (tile, group) list so
+// that the residual-row scratch (trimmed runs) is per resident workgroup, not per tile.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(1024) void k_eval_cubes_stream(DevTables T, const float4* __restrict__ rot_all, int slot0, int level0,
+                                                            const int2* __restrict__ groups, int ngroups, const float* __restrict__ cubes, int n,
+                                                            float* __restrict__ ub_out, float* __restrict__ lb_out) {
+    __shared__ TileShm<1024> sh;
+    const int tid = threadIdx.x;
+    const int Nd = T.Nd;
+    float* rows = T.srows ? T.srows + (size_t)blockIdx.x * TC * T.NdP : nullptr;
+    const int tiles = (n + TC - 1) / TC;
+    const long long total = (long long)tiles * ngroups;
+    for (long long w = blockIdx.x; w < total; w += gridDim.x) {
+        const int g = (int)(w / tiles), base = (int)(w % tiles) * TC;
+        int slot = slot0, rot_level = level0;
+        if (groups) { const int2 gg = groups[g]; slot = gg.x; rot_level = gg.y; }
+        if (tid < TC) {
+            const int j = tid, c = min(base + j, n - 1);
+            const float x = cubes[4 * c], y = cubes[4 * c + 1], z = cubes[4 * c + 2], wd = cubes[4 * c + 3];
+            sh.cube[j][0] = x; sh.cube[j][1] = y; sh.cube[j][2] = z; sh.cube[j][3] = wd;
+            sh.cen[j][0] = x + wd / 2; sh.cen[j][1] = y + wd / 2; sh.cen[j][2] = z + wd / 2;
+            sh.mtd[j] = (float)(SQRT3_D / 2.0 * wd);
+        }
+        __syncthreads();
+        if (tid == 0) {
+            bool row = true;
+            for (int j = 1; j < TC; j++) row = row && sh.cen[j][1] == sh.cen[0][1] && sh.cen[j][2] == sh.cen[0][2];
+            sh.ctl[2] = row ? 1 : 0;
+        }
+        __syncthreads();
+        sweep_stream<false>(T, sh, rot_all + (size_t)slot * Nd, rot_level >= 0 ? T.maxRotDis + (size_t)rot_level * Nd : nullptr, rows, T.NdP);
+        if (tid < TC && base + tid < n) { ub_out[(size_t)g * n + base + tid] = sh.ub[tid]; lb_out[(size_t)g * n + base + tid] = sh.lb[tid]; }
+        __syncthreads();
     }
 }
 
@@ -1160,6 +1503,7 @@ struct goicp_engine {
     float* d_cubes; float* d_ub; float* d_lb; int cube_cap; int2* d_groups; std::vector<int2> groups_host;
     double* d_Rt; float* d_Rtf; float* d_dist; int* d_int; float* d_lat; int lat_cap; int* d_cnt; float* d_fp;
     int block, ppt; size_t dyn_lds; size_t dyn_lds_bnb; int heap_lds_nodes; int rbuf_floats; int fp_lds;
+    int streamed; size_t stream_wgs;        // streaming path (Nd > 8192): scratch sized for this many resident workgroups
     unsigned max_pops;
     uint64_t n_cubes, n_lookups; double kernel_ms;
     std::string err;
@@ -1190,6 +1534,8 @@ extern "C" void goicp_engine_destroy(goicp_engine* h) {
     for (void* p : h->allocs) (void)hipFree(p);
     if (h->d_heaps) (void)hipFree(h->d_heaps);
     if (h->d_heap_big) (void)hipFree(h->d_heap_big);
+    if (h->T.srot) (void)hipFree(h->T.srot);
+    if (h->T.srows) (void)hipFree(h->T.srows);
     if (h->d_fpscratch) (void)hipFree(h->d_fpscratch);
     if (h->ev0) (void)hipEventDestroy(h->ev0);
     if (h->ev1) (void)hipEventDestroy(h->ev1);
@@ -1212,7 +1558,9 @@ static void pick_geometry(goicp_engine* h) {
     // lanes x points-per-lane; the residuals of a tile (TC x PPT floats per lane) stay in registers across the
     // selection passes, so large clouds use 512-lane workgroups (256 VGPRs per lane) instead of 1024 (128 VGPRs)
     const int Nd = h->T.Nd;
-    if (Nd <= 256) { h->block = 256; h->ppt = 1; }
+    h->streamed = Nd > 8192;
+    if (h->streamed) { h->block = 1024; h->ppt = 1; }          // cloud streamed from HBM per tile (sweep_stream)
+    else if (Nd <= 256) { h->block = 256; h->ppt = 1; }
     else if (Nd <= 512) { h->block = 256; h->ppt = 2; }
     else if (Nd <= 1024) { h->block = 1024; h->ppt = 1; }
     else if (Nd <= 2048) { h->block = 1024; h->ppt = 2; }
@@ -1236,10 +1584,11 @@ extern "C" int goicp_engine_create(const goicp_engine_desc* d, goicp_engine** ou
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || d->device_id < 0 || d->device_id >= ndev) return GOICP_ERR_NO_DEVICE;
     if (d->S <= 0 || !d->dt_dist || d->Nd <= 0 || !d->data_xyz || !d->weights || !d->maxRotDis || d->Nm < 0) return GOICP_ERR_ARG;
     if (d->regularizationNeighbors > 0.f) return GOICP_ERR_ARG;
-    if (d->Nd > 8192) return GOICP_ERR_ARG;       // register-resident cloud: 1024 lanes x 8 points
+    if (d->Nd > (1 << 20)) return GOICP_ERR_ARG;  // up to 8192 points the cloud is register-resident; above that it is streamed (geometric error only)
     if (d->doTrim && (d->inlierNum < 1 || d->inlierNum > d->Nd)) return GOICP_ERR_ARG;
     const bool use_compat = d->regularization > 0.f;
     const bool use_fpfh = d->regularizationFPFH > 0.f;        // entered for any cfpfh once regularizationFPFH>0 (jly_goicp.cpp:460)
+    if (d->Nd > 8192 && (use_compat || use_fpfh)) return GOICP_ERR_ARG;   // streamed clouds: geometric error only (the reference's own penalty constant overflows int above 46 340 points)
     const bool have_tables = d->nearest_occ && d->cell_color && d->cell_ptr && d->cell_idx && d->model_color && d->data_color;
     if ((use_compat || use_fpfh) && !have_tables) return GOICP_ERR_ARG;
     if (use_fpfh && (!d->model_fpfh || !d->data_fpfh)) return GOICP_ERR_ARG;
@@ -1247,6 +1596,7 @@ extern "C" int goicp_engine_create(const goicp_engine_desc* d, goicp_engine** ou
     goicp_engine* h = new goicp_engine();
     memset(&h->T, 0, sizeof h->T);
     h->device = d->device_id; h->stream = nullptr; h->ev0 = h->ev1 = nullptr;
+    h->streamed = 0; h->stream_wgs = 0;
     h->d_heaps = nullptr; h->d_fpscratch = nullptr; h->heap_cap = 8192; h->heap_jobs = 0; h->fp_blocks = 0; h->d_heap_big = nullptr; h->heap_big_cap = 0;
     h->n_cubes = h->n_lookups = 0; h->kernel_ms = 0; h->max_pops = 200000000u;
 #define CR(call) do { int rc_ = (call); if (rc_ != GOICP_OK) { std::string m = h->err; goicp_engine_destroy(h); fprintf(stderr, "goicp_engine_create: %s\n", m.c_str()); return rc_; } } while (0)
@@ -1265,6 +1615,7 @@ extern "C" int goicp_engine_create(const goicp_engine_desc* d, goicp_engine** ou
     { const char* e = getenv("GOICP_DBG"); T.dbg = e ? atoi(e) : 0; }
     { const char* e = getenv("GOICP_MAX_POPS"); if (e) h->max_pops = (unsigned)atoll(e); }
     { const char* e = getenv("GOICP_HEAP_CAP"); if (e && atoi(e) >= 16) h->heap_cap = atoi(e); }      // test knob: small queue slabs
+    T.NdP = (d->Nd + 1023) & ~1023; T.srot = nullptr; T.srows = nullptr;
     T.exact = (d->parity_mode && d->Nd <= 1024) ? 1 : 0;   // 2*TC*Nd floats of LDS next to the static tile state and the LDS heap
     const size_t ncell = (size_t)d->S * d->S * d->S;
     float* p_dist; CR(dev_upload(h, d->dt_dist, ncell, &p_dist)); T.dist = p_dist;
@@ -1367,6 +1718,7 @@ extern "C" int goicp_engine_create(const goicp_engine_desc* d, goicp_engine** ou
                            if (h->dyn_lds) CRH(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_eval_cubes<B, P, TC>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->dyn_lds)); } while (0)
         DISPATCH_GEOM(h, SETATTR);
 #undef SETATTR
+        if (h->streamed) CRH(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_inner_bnb<1024, 1, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->dyn_lds_bnb));
     }
 #undef CR
 #undef CRH
@@ -1417,7 +1769,31 @@ static int ensure_fpscratch(goicp_engine* h, size_t blocks) {
     return GOICP_OK;
 }
 
+static int ensure_stream_scratch(goicp_engine* h, size_t wgs, bool need_rot) {
+    // per resident workgroup: rotated cloud (search kernel only) + TC residual rows (trimmed runs only)
+    if (wgs <= h->stream_wgs) return GOICP_OK;
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    if (h->T.srot) { (void)hipFree(h->T.srot); h->T.srot = nullptr; }
+    if (h->T.srows) { (void)hipFree(h->T.srows); h->T.srows = nullptr; }
+    h->stream_wgs = 0;
+    (void)need_rot;
+    HIPCHK(h, hipMalloc((void**)&h->T.srot, wgs * (size_t)h->T.NdP * sizeof(float4)));
+    if (h->T.doTrim) HIPCHK(h, hipMalloc((void**)&h->T.srows, wgs * (size_t)TC * h->T.NdP * sizeof(float)));
+    h->stream_wgs = wgs;
+    return GOICP_OK;
+}
+
 static int launch_eval(goicp_engine* h, int slot, int rot_level, const int2* groups_dev, int ngroups, const void* cubes_dev, int n, void* ub_dev, void* lb_dev) {
+    if (h->streamed) {
+        const long long total = (long long)((n + TC - 1) / TC) * ngroups;
+        const int wgs = (int)std::min<long long>(total, 512);          // two per CU
+        int rcs = ensure_stream_scratch(h, (size_t)wgs, false);
+        if (rcs != GOICP_OK) return rcs;
+        hipLaunchKernelGGL(k_eval_cubes_stream, dim3(wgs), dim3(1024), 0, h->stream, h->T, h->d_rot, slot, rot_level, groups_dev, ngroups, (const float*)cubes_dev, n, (float*)ub_dev, (float*)lb_dev);
+        HIPCHK(h, hipGetLastError());
+        h->n_cubes += (uint64_t)n * ngroups; h->n_lookups += (uint64_t)n * ngroups * h->T.Nd;
+        return GOICP_OK;
+    }
     const int tiles = (n + TC - 1) / TC;
     int rc = ensure_fpscratch(h, (size_t)tiles * ngroups);
     if (rc != GOICP_OK) return rc;
@@ -1513,11 +1889,13 @@ static int ensure_big_heap(goicp_engine* h, int cap) {
 static int run_bnb(goicp_engine* h, const goicp_bnb_job* jobs, int njobs, goicp_bnb_result* results, HeapNode* heaps, int cap) {
     int rc = ensure_fpscratch(h, (size_t)njobs);
     if (rc != GOICP_OK) return rc;
+    if (h->streamed) { rc = ensure_stream_scratch(h, (size_t)njobs, true); if (rc != GOICP_OK) return rc; }
     HIPCHK(h, hipMemcpyAsync(h->d_jobs, jobs, (size_t)njobs * sizeof(goicp_bnb_job), hipMemcpyHostToDevice, h->stream));
     HIPCHK(h, hipEventRecord(h->ev0, h->stream));
 #define CALL(B, P) do { if (h->T.use_compat || h->T.use_fpfh) hipLaunchKernelGGL((k_inner_bnb<B, P, true>), dim3(njobs), dim3(B), h->dyn_lds_bnb, h->stream, h->T, h->d_jobs, h->d_results, heaps, cap, h->d_fpscratch, h->max_pops, h->heap_lds_nodes, h->rbuf_floats, h->fp_lds); \
                         else hipLaunchKernelGGL((k_inner_bnb<B, P, false>), dim3(njobs), dim3(B), h->dyn_lds_bnb, h->stream, h->T, h->d_jobs, h->d_results, heaps, cap, h->d_fpscratch, h->max_pops, h->heap_lds_nodes, h->rbuf_floats, h->fp_lds); } while (0)
-    DISPATCH_GEOM(h, CALL);
+    if (h->streamed) hipLaunchKernelGGL((k_inner_bnb<1024, 1, false, true>), dim3(njobs), dim3(1024), h->dyn_lds_bnb, h->stream, h->T, h->d_jobs, h->d_results, heaps, cap, h->d_fpscratch, h->max_pops, h->heap_lds_nodes, h->rbuf_floats, h->fp_lds);
+    else DISPATCH_GEOM(h, CALL);
 #undef CALL
     HIPCHK(h, hipGetLastError());
     HIPCHK(h, hipEventRecord(h->ev1, h->stream));
@@ -1532,8 +1910,9 @@ extern "C" int goicp_engine_inner_bnb_batch(goicp_engine* h, const goicp_bnb_job
     HIPCHK(h, hipSetDevice(h->device));
     for (int j = 0; j < njobs; j++) if (jobs[j].rot_level >= GOICP_MAXROTLEVEL) return GOICP_ERR_ARG;
     int worst = GOICP_OK;
-    for (int off = 0; off < njobs; off += h->job_cap) {
-        const int m = std::min(h->job_cap, njobs - off);
+    const int job_cap = h->streamed ? std::min(h->job_cap, 256) : h->job_cap;
+    for (int off = 0; off < njobs; off += job_cap) {
+        const int m = std::min(job_cap, njobs - off);
         int rc = ensure_heaps(h, (size_t)m);
         if (rc != GOICP_OK) return rc;
         rc = run_bnb(h, jobs + off, m, results + off, h->d_heaps, h->heap_cap);

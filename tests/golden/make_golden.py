@@ -178,6 +178,7 @@ def main():
         "pair1_S50": (P1, dict(distTransSize=50, MSEThresh=0.02)),
         "pair1_S100_geo": (P1, dict(distTransSize=100, MSEThresh=0.05, regularization=0.0, ponderation=0)),
         "pair2_default": (P2, {}),
+        "pair1_S300": (P1, dict(distTransSize=300)),          # BASELINE configs[1]: cavity pair 1 on a 300^3 DT
     }
     for nm, (P, over) in variants.items():
         r, v = new_ref(P, **over)

@@ -62,9 +62,15 @@ def test_unsupported_configurations_fail_at_create():
         goicp_amd.Engine(do_trim=True, **dict(base, inlier_num=0))
     with pytest.raises(goicp_amd.EngineError):          # no such device
         goicp_amd.Engine(device_id=63, **base)
-    big = np.zeros((9000, 3), np.float32)
-    with pytest.raises(goicp_amd.EngineError):          # register-resident cloud limit (8192 points)
-        goicp_amd.Engine(**dict(base, data_xyz=big, weights=np.ones(9000, np.float32), maxrotdis=np.zeros(20 * 9000, np.float32), inlier_num=9000))
+    # clouds above 8192 points are streamed and support the geometric error only: penalties on such a cloud are refused
+    S = int(H["geom"][7]); nb = 9000
+    near = (H["nearest3"][:, 2].astype(np.int64) * S + H["nearest3"][:, 1]) * S + H["nearest3"][:, 0]
+    big = dict(base, data_xyz=np.zeros((nb, 3), np.float32), weights=np.ones(nb, np.float32), maxrotdis=np.zeros(20 * nb, np.float32), inlier_num=nb)
+    with pytest.raises(goicp_amd.EngineError):
+        goicp_amd.Engine(reg=0.0005, nearest=near, cell_color=H["cellc"], cell_ptr=H["cell_ptr"], cell_idx=H["cell_idx"], model_color=P["tc"],
+                         data_color=np.zeros(nb, np.int32), **big)
+    e = goicp_amd.Engine(**big)                         # the same cloud without penalties is accepted
+    e.close()
 
 
 def test_more_than_16_colour_codes_is_rejected():

@@ -119,7 +119,8 @@ def test_point_eval_and_icp_nn_against_oracle():
     e.close()
 
 
-REG = ["pair1_default", "pair1_fpfh", "pair1_fpfh33", "pair1_color8", "pair1_norm1", "pair1_trim", "pair1_S50", "pair1_S100_geo"]
+REG = ["pair1_default", "pair1_fpfh", "pair1_fpfh33", "pair1_color8", "pair1_norm1", "pair1_trim", "pair1_S50", "pair1_S100_geo",
+       "pair1_S300"]         # pair1_S300 = BASELINE configs[1]: the shipped cavity pair on a 300^3 DT
 
 
 @pytest.mark.parametrize("name", REG)
@@ -222,12 +223,13 @@ def test_synthetic_cloud_against_oracle(n, S, trim):
     e.close()
 
 
+@pytest.mark.parametrize("n", [2000, 9000])
 @pytest.mark.parametrize("kind", ["outside_grid", "duplicates", "wide_range", "norm1_untrimmed"])
-def test_large_cloud_sweep_edge_cases_against_oracle(kind):
+def test_large_cloud_sweep_edge_cases_against_oracle(kind, n):
     """The histogram-select sweep used above 1024 points (fp64 sums): cubes that push most points out of the DT grid
     (extension path), clouds whose residuals crowd one histogram bin or span more than the 8-octave window (generic byte
     passes), and the norm-1 untrimmed sums -- each against the oracle's cube evaluation."""
-    n, S = 2000, 60
+    S = 60
     P = synth_pair(n, seed=77)
     s = P["s"].copy(); trim = 0.1; norm = 2
     rng = np.random.default_rng(5)
@@ -264,6 +266,40 @@ def test_large_cloud_sweep_edge_cases_against_oracle(kind):
     e.close()
 
 
+@pytest.mark.parametrize("trim", [0.0, 0.1])
+def test_streamed_cloud_against_oracle(trim):
+    """Clouds above 8192 points are streamed from HBM (sweep_stream): cube tables, the extension path, the generic byte
+    passes and a bounded InnerBnB against the oracle on a 12 000-point cloud."""
+    n, S = 12000, 60
+    P = synth_pair(n, seed=4242)
+    v, _ = cfg_vector(distTransSize=S, trimFraction=trim, regularization=0.0, ponderation=0, MSEThresh=0.01)   # loose: keeps the oracle's search short
+    o = oracle_for(P, v); o.initialize()
+    dist, near3, cc, _ = o.dt_dump()
+    e = goicp_amd.Engine(S=S, geom4=(o.geom[0], o.geom[2], o.geom[4], o.geom[6]), dist=dist, data_xyz=P["s"], weights=o.weights(),
+                         maxrotdis=o.maxrotdis(), model_xyz=P["t"], inlier_num=o.inlier_num(), do_trim=trim >= 0.001, norm=2, parity_mode=1)
+    rng = np.random.default_rng(99)
+    for it in range(2):
+        R = o.axis_angle(rng.uniform(-2, 2, 3).astype(np.float32))
+        o.rotate(R); e.set_rotation(it, R)
+        lvl = (-1, 2)[it]
+        cubes = []
+        for L in (1, 3, 5):
+            w = np.float32(1.0 / 2 ** L)
+            for a in rng.integers(0, 2 ** L, (6, 3)):
+                cubes.append([np.float32(-0.5) + a[0] * w, np.float32(-0.5) + a[1] * w, np.float32(-0.5) + a[2] * w, w])
+        cubes = np.array(cubes, np.float32)
+        cubes[::5, :3] += np.float32([1.9, -2.2, 0.4])          # mostly outside the grid
+        ub, lb = e.eval_cubes(it, lvl, cubes)
+        oub, olb = o.eval_cubes(lvl, cubes)
+        assert close(ub, oub, False, n) and close(lb, olb, False, n), (np.abs(ub - oub).max(), np.abs(lb - olb).max())
+        E = np.float32(oub.min() * 1.2)
+        o.set_opt_error(E)
+        val, node = o.inner_bnb(lvl)
+        r = e.inner_bnb(R=R, level=lvl, E=E, sse=np.float32(o.sse_thresh()), init=(-0.5, -0.5, -0.5, 1.0))
+        assert r["status"] == 0 and close(r["val"], val, False, n), (r, val)
+    e.close()
+
+
 def test_multi_group_launch_equals_single_launches():
     H = load_hotpath("pair1_default"); P = load_clouds("pair1")
     import torch
@@ -282,15 +318,15 @@ def test_multi_group_launch_equals_single_launches():
     e.close()
 
 
-def test_full_size_properties_300_cubed():
-    """BASELINE config-3 shape (N=5000, 300^3 DT, trim 0.1): size-independent properties of the cube sweep.
+@pytest.mark.parametrize("n,S,trim", [(5000, 300, 0.1), (50000, 500, 0.0), (20000, 200, 0.1)])
+def test_full_size_properties(n, S, trim):
+    """BASELINE config-3 shape (N=5000, 300^3 DT, trim 0.1), config-5 shape (N=50000, 500^3 DT, untrimmed; streamed
+    cloud) and a trimmed streamed cloud: size-independent properties of the cube sweep.
     (i) a cube evaluated alone == the same cube inside a large batch; (ii) lb <= ub; (iii) bounds are monotone in
     the rotation-uncertainty level (larger rho => smaller residuals); (iv) ub of a zero-width cube == the
     point_eval residual sum at that translation."""
-    n, S = 5000, 300
     P = synth_pair(n)
-    import time
-    g = goicp_amd.GoICP(cfg_vector(distTransSize=S, trimFraction=0.1, regularization=0.0, ponderation=0, MSEThresh=0.001)[0])
+    g = goicp_amd.GoICP(cfg_vector(distTransSize=S, trimFraction=trim, regularization=0.0, ponderation=0, MSEThresh=0.001)[0])
     g.set_clouds(P["t"], P["s"]); g.build_dt(); g.initialize()
     e = g.engine()
     R = np.eye(3, dtype=np.float32)
@@ -311,6 +347,10 @@ def test_full_size_properties_300_cubed():
     k = g.inlier_num()
     ref = np.sort(d.astype(np.float64) ** 2)[:k].sum()
     assert abs(ubz[0] - ref) <= 1e-5 * ref and abs(lbz[0] - ubz[0]) <= 1e-6 * ref
+    # (v) a bounded search from the root returns an upper bound that some evaluated cube attains and never exceeds the incumbent
+    E = np.float32(ub.min() * 2)
+    r = e.inner_bnb(R=R, level=-1, E=E, sse=np.float32(g.sse_thresh()), init=(-0.5, -0.5, -0.5, 1.0), max_pops=40)
+    assert r["status"] in (0, 5) and r["val"] <= E and r["pops"] <= 41
     g.close()
 
 
