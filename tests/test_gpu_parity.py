@@ -429,3 +429,21 @@ def test_c3_headline_pair_matches_reference_known_answer():
     assert np.abs(out["R"] - np.array(G["R"])).max() < 1e-5 and np.abs(out["t"] - np.array(G["t"])).max() < 1e-5
     assert out["stats"]["trans_pops"] == G["pops"]
     g.close()
+
+
+def test_streamed_registration_matches_reference_known_answer():
+    """A 9 000-point pair (above the 8192-point register-resident limit: cloud streamed from HBM) through the whole
+    Register(): the compiled reference's answer on the same seeded inputs is in tests/golden/stream9k_reference.json
+    (generator: tests/golden/make_synth_reference.py; 10.3 s on the build container). Sums are fp64 here, so R, t, error
+    to 1e-5; the search visits the same number of translation nodes."""
+    import json
+    from goicp_amd.synth import synth_pair
+    G = json.load(open(os.path.join(GOLDEN, "stream9k_reference.json")))
+    P = synth_pair(G["n"], seed=G["seed"], theta_range=tuple(G["pair"]["theta_range"]), outlier_frac=G["pair"]["outlier_frac"])
+    g = goicp_amd.GoICP(goicp_amd.cfg_vector(**G["cfg"])); g.set_clouds(P["t"], P["s"]); g.build_dt()
+    out = g.register()
+    assert abs(float(out["error"]) - G["error"]) <= 1e-5 * G["error"]
+    assert np.abs(out["R"] - np.array(G["R"])).max() < 1e-5 and np.abs(out["t"] - np.array(G["t"])).max() < 1e-5
+    assert out["stats"]["trans_pops"] == G["pops"]        # (the reference's rotation-queue counter includes its final drain: not comparable)
+    assert [a for a, _ in out["trace"]] == [a for a, _ in G["trace"]]
+    g.close()

@@ -129,6 +129,32 @@ def test_register_demo_rand_known_answers():
 
 
 @pytest.mark.slow
+def test_register_pair1_on_300_cubed_known_answer():
+    """BASELINE configs[1]: the shipped cavity pair on a 300^3 DT (error 8.30483, 132 incompatibilities)."""
+    G = load_register()["pair1_S300"]
+    P = load_clouds("pair1")
+    v, _ = cfg_vector(**G["cfg"])
+    out = oracle_for(P, v).register()
+    assert float(out["error"]) == G["error"] and out["comp"] == G["comp"] and float("%g" % G["error"]) == 8.30483 and G["Nd"] - G["comp"] == 132
+    assert np.abs(out["R"] - np.array(G["R"])).max() < 1e-12 and np.abs(out["t"] - np.array(G["t"])).max() < 1e-12
+
+
+def test_register_streamed_pair_known_answer():
+    """The oracle on the repo's seeded 9 000-point synthetic pair against the compiled reference's result
+    (tests/golden/stream9k_reference.json, generator tests/golden/make_synth_reference.py)."""
+    import json
+    from helpers import synth_pair
+    G = json.load(open(os.path.join(GOLDEN, "stream9k_reference.json")))
+    P = synth_pair(G["n"], seed=G["seed"], theta_range=tuple(G["pair"]["theta_range"]), outlier_frac=G["pair"]["outlier_frac"])
+    v, _ = cfg_vector(**G["cfg"])
+    o = Oracle(); o.set_config(v); o.set_clouds(P["t"], P["s"]); o.build_dt()
+    out = o.register()
+    assert float(out["error"]) == G["error"]
+    assert np.abs(out["R"] - np.array(G["R"])).max() < 1e-12 and np.abs(out["t"] - np.array(G["t"])).max() < 1e-12
+    assert [(a, float("%g" % b)) for a, b in error_trace(out["log"])] == [tuple(x) for x in G["trace"]]
+
+
+@pytest.mark.slow
 def test_register_pair2_known_answer():
     G = load_register()["pair2_default"]
     P = load_clouds("pair2")
