@@ -1503,6 +1503,7 @@ struct goicp_engine {
     float* d_cubes; float* d_ub; float* d_lb; int cube_cap; int2* d_groups; std::vector<int2> groups_host;
     double* d_Rt; float* d_Rtf; float* d_dist; int* d_int; float* d_lat; int lat_cap; int* d_cnt; float* d_fp;
     int block, ppt; size_t dyn_lds; size_t dyn_lds_bnb; int heap_lds_nodes; int rbuf_floats; int fp_lds;
+    int resident_jobs;                       // search workgroups resident at once (CUs x occupancy of the chosen k_inner_bnb)
     int streamed; size_t stream_wgs;        // streaming path (Nd > 8192): scratch sized for this many resident workgroups
     unsigned max_pops;
     uint64_t n_cubes, n_lookups; double kernel_ms;
@@ -1570,7 +1571,7 @@ static void pick_geometry(goicp_engine* h) {
     h->dyn_lds = h->T.exact ? (size_t)2 * TC * Nd * sizeof(float) : 0;      // ub and lb addend rows (untrimmed) / residual rows (trimmed)
     // k_inner_bnb keeps the top of its queue in LDS behind the residual rows (24 B per node)
     h->rbuf_floats = (int)(h->dyn_lds / sizeof(float));
-    h->heap_lds_nodes = 2048;
+    h->heap_lds_nodes = 1024;             // 24 KB: two 256-lane search workgroups fit one CU's LDS next to their tile state
     { const char* e = getenv("GOICP_HEAP_LDS"); if (e && atoi(e) >= 0 && atoi(e) <= 2048) h->heap_lds_nodes = atoi(e); }   // test knob
     h->dyn_lds_bnb = h->dyn_lds + (size_t)h->heap_lds_nodes * sizeof(HeapNode);
     h->fp_lds = 0;
@@ -1719,6 +1720,17 @@ extern "C" int goicp_engine_create(const goicp_engine_desc* d, goicp_engine** ou
         DISPATCH_GEOM(h, SETATTR);
 #undef SETATTR
         if (h->streamed) CRH(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_inner_bnb<1024, 1, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->dyn_lds_bnb));
+        {
+            hipDeviceProp_t prop; CRH(hipGetDeviceProperties(&prop, h->device));
+            int nb = 0;
+            const bool pen = T.use_compat || T.use_fpfh;
+#define OCC(B, P) do { if (pen) CRH(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_inner_bnb<B, P, true>, B, h->dyn_lds_bnb)); \
+                       else CRH(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_inner_bnb<B, P, false>, B, h->dyn_lds_bnb)); } while (0)
+            if (h->streamed) CRH(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_inner_bnb<1024, 1, false, true>, 1024, h->dyn_lds_bnb));
+            else DISPATCH_GEOM(h, OCC);
+#undef OCC
+            h->resident_jobs = std::max(1, nb) * std::max(1, prop.multiProcessorCount);
+        }
     }
 #undef CR
 #undef CRH
@@ -1734,6 +1746,7 @@ extern "C" int goicp_engine_debug_times(goicp_engine* h, unsigned long long* out
 }
 
 extern "C" int goicp_engine_num_slots(const goicp_engine* h) { return h ? h->nslots : 0; }
+extern "C" int goicp_engine_resident_jobs(const goicp_engine* h) { return h ? h->resident_jobs : 0; }
 extern "C" void* goicp_engine_stream(const goicp_engine* h) { return h ? (void*)h->stream : nullptr; }
 
 extern "C" int goicp_engine_synchronize(goicp_engine* h) {

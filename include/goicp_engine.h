@@ -109,6 +109,9 @@ const char* goicp_engine_last_error(const goicp_engine* h);
 /* number of rotation slots for eval_cubes (each holds one rotated copy of the data cloud on the device) */
 int goicp_engine_set_rotation(goicp_engine* h, int slot, const float* R9);
 int goicp_engine_num_slots(const goicp_engine* h);
+/* InnerBnB jobs (one workgroup each) that are resident on the device at once for this engine's geometry: a batch of at most
+ * this many jobs runs as one wave of workgroups. The host's speculative batching sizes its launches with it. */
+int goicp_engine_resident_jobs(const goicp_engine* h);
 
 /* (cube) -> (ub, lb) for n cubes given as x,y,z,w quadruples, rotation slot `slot`, rot_level as in the job */
 int goicp_engine_eval_cubes(goicp_engine* h, int slot, int rot_level, const float* cubes, int n, float* ub, float* lb);

@@ -92,3 +92,13 @@ def test_protein_transform_reproduces_shipped_file(tmp_path):
     out = os.path.join(d, "got.mol2")
     assert goicp_amd.apply_transformation_protein(os.path.join(DATA, "output", "similar1_rescaled.txt"), chain, out)
     assert open(out).read() == open(want).read()
+
+
+def test_parallel_partition_formulation_equals_the_sequential_loop(tmp_path):
+    """wave_intro_select (engine.hip) computes the reference's partition (jly_sorting.hpp:282-303) from ranks instead of a
+    cell-by-cell scan; tests/csrc/partition_check.c checks that formulation against the sequential loop on random rows."""
+    import subprocess
+    exe = str(tmp_path / "partition_check")
+    subprocess.check_call(["gcc", "-O2", "-o", exe, os.path.join(os.path.dirname(__file__), "csrc", "partition_check.c")])
+    out = subprocess.run([exe, "300000"], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0 and out.stdout.strip() == "bad=0", out.stdout
