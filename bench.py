@@ -224,7 +224,7 @@ def main():
         if not default_shape:
             traffic = None                      # the committed PMC summary belongs to the default shape only
         geom = [(256, 1, 256), (512, 2, 256), (1024, 1, 1024), (2048, 2, 1024), (4096, 4, 1024), (5120, 5, 1024), (8192, 16, 512)]
-        kname = next(("k_eval_cubes<%d,%d>" % (b, p) for lim, p, b in geom if nd <= lim), "k_eval_cubes_stream")
+        kname = next(("k_eval_cubes<%d,%d,8>" % (b, p) for lim, p, b in geom if nd <= lim), "k_eval_cubes_stream")
         label = "configs[2]" if default_shape else ("configs[4] shape" if nd >= 50000 else "non-default shape")
         line = {
             "metric": "translation_bnb_cube_evals_per_sec", "value": value, "unit": "cube-evals/s", "n_gpus": world, "steps": args.steps,

@@ -420,12 +420,21 @@ __device__ __forceinline__ void sweep_tile(const DevTables& T, TileShm<BLOCK>& s
             const float sub = is_lb ? sh.mtd[j] : 0.f;
             const bool sq = T.norm == 2, lin = T.norm == 1;
             float acc = 0.f;
-            for (int i = 0; i < T.inlierNum; i++) {
-                const float e = rr[i] - sub;                       // (d - 0 == d exactly for the ub chain)
+            auto add = [&](float d) {
+                const float e = d - sub;                           // (d - 0 == d exactly for the ub chain)
                 float term = sq ? e * e : (lin ? e : 0.f);
                 if (is_lb && !(e > 0.f)) term = 0.f;
                 acc += term;
+            };
+            int i = 0;
+            for (; i + 16 <= T.inlierNum; i += 16) {                // 16 LDS reads in flight, then the 16 dependent adds
+                float v[16];
+#pragma unroll
+                for (int q = 0; q < 16; q++) v[q] = rr[i + q];
+#pragma unroll
+                for (int q = 0; q < 16; q++) add(v[q]);
             }
+            for (; i < T.inlierNum; i++) add(rr[i]);
             if (is_lb) sh.lb[j] = acc; else sh.ub[j] = acc;
         }
         __syncthreads();
@@ -468,9 +477,6 @@ __device__ __forceinline__ void sweep_tile(const DevTables& T, TileShm<BLOCK>& s
         __syncthreads();
         return;
     }
-    // ---- inlier threshold per cube: k-th smallest residual by 4x8-bit radix select on the float bits
-    //      (residuals are >= 0, so the bit pattern orders like the value). Replaces intro_select
-    //      (reference jly_sorting.hpp:229): the selected multiset is identical, the order is not needed.
     // ---- inlier threshold per cube = the inlierNum-th smallest residual, by MSB-first radix select on the float bit
     //      pattern (residuals are >= 0, so the pattern orders like the value) with LDS histograms. Replaces intro_select
     //      (reference jly_sorting.hpp:229): the selected multiset is the same, the order is not needed (order-free sums).
@@ -826,6 +832,22 @@ __device__ __forceinline__ void heap_up(const HeapStore& a, int hole, const Heap
         a.set(hole, a.get(par)); hole = par; par = (hole - 1) / 2;
     }
     a.set(hole, v);
+}
+// heap_up for a whole wave (uniform hole and v): the ancestors of the hole are known up front, so lane k fetches ancestor k,
+// one ballot tells how many of them v passes (the leading run of "ancestor is lower"), those ancestors drop one slot down
+// the path in parallel and v lands above them -- the arrangement std::push_heap's loop produces, in one round trip to
+// the queue instead of one per level.
+__device__ __forceinline__ void heap_up_wave(const HeapStore& a, int hole, const HeapNode& v, int lane) {
+    const int depth = 31 - __clz(hole + 1);                      // ancestors: ((hole+1) >> (k+1)) - 1, k = 0 .. depth-1
+    const bool act = lane < depth;
+    HeapNode nk = v; bool rises = false;
+    if (act) { nk = a.get(((hole + 1) >> (lane + 1)) - 1); rises = key_lower(nk.lb, nk.w, v.lb, v.w); }
+    const unsigned long long up = __ballot(rises);
+    const int m = min(depth, __ffsll((long long)~up) - 1);       // lanes >= depth never rise, so ~up is never 0
+    wave_sync_lds();
+    if (lane < m) a.set(((hole + 1) >> lane) - 1, nk);            // ancestor k drops into the slot below it on the path
+    if (lane == 0) a.set(((hole + 1) >> m) - 1, v);
+    wave_sync_lds();
 }
 __device__ __forceinline__ void heap_pop(const HeapStore& a, int& n) {
     if (n > 1) {
@@ -1193,8 +1215,9 @@ __global__ __launch_bounds__(BLOCK) void k_inner_bnb(DevTables T, const goicp_bn
     unsigned pops = 0, cubes = 0;
     if (tid == 0) {
         HeapNode root; root.x = job.init[0]; root.y = job.init[1]; root.z = job.init[2]; root.w = job.init[3]; root.ub = 0.f; root.lb = job.init_lb;
-        heap.set(0, root); hn = 1;
+        heap.set(0, root);
     }
+    hn = 1;
     const bool penalties = PEN && (T.use_compat || T.use_fpfh);
     const bool timing = (T.dbg & 32) && T.dbg_times && blockIdx.x == 0 && tid == 0;
     unsigned long long tph[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tlast = timing ? clock64() : 0ull;
@@ -1214,6 +1237,7 @@ __global__ __launch_bounds__(BLOCK) void k_inner_bnb(DevTables T, const goicp_bn
             }
             sh.ctl[0] = done;
         }
+        if (tid < 64) hn = __shfl(hn, 0, 64);                    // the pop above ran on lane 0 only
         STAMP(0);
         __syncthreads();
         if (sh.ctl[0]) break;
@@ -1263,8 +1287,9 @@ __global__ __launch_bounds__(BLOCK) void k_inner_bnb(DevTables T, const goicp_bn
             }
             __syncthreads();
         }
-        if (tid == 0) {
-            // ... and lane 0 replays the order-dependent part: incumbent update, prune, push (reference jly_goicp.cpp:554-575)
+        if (tid < 64) {
+            // ... and wave 0 replays the order-dependent part with uniform control flow (every lane carries the same search
+            // state; lane 0's copy is the one reported): incumbent update, prune, push (reference jly_goicp.cpp:554-575)
             cubes += 8;
             for (int j = 0; j < TC; j++) {
                 const float ub = sh.ub[j], lb = sh.lb[j];
@@ -1272,7 +1297,7 @@ __global__ __launch_bounds__(BLOCK) void k_inner_bnb(DevTables T, const goicp_bn
                 if (lb >= optErrorT) continue;                                  // reference jly_goicp.cpp:568
                 HeapNode nd; nd.x = sh.cube[j][0]; nd.y = sh.cube[j][1]; nd.z = sh.cube[j][2]; nd.w = sh.cube[j][3]; nd.ub = ub; nd.lb = lb;
                 hn++;
-                heap_up(heap, hn - 1, nd);
+                heap_up_wave(heap, hn - 1, nd, tid);
             }
         }
         STAMP(5);
