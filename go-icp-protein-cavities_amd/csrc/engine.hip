@@ -167,11 +167,11 @@ __device__ __forceinline__ void hist_add(unsigned* row, unsigned key, bool take,
 }
 
 // ---------------------------------------------------------------------------------------------
-// intro_select of the reference (jly_sorting.hpp:34-313) with its exact swap sequence, run by ONE lane on a residual row in
+// intro_select of the reference (jly_sorting.hpp:34-313) with its exact swap sequence, run by one wave on a residual row in
 // LDS. Parity mode uses it for trimmed runs of small clouds: the permutation it leaves behind fixes the order of the
 // float sums that follow (jly_goicp.cpp:389-415), so the bounds come out bit-identical to the reference's.
 // ---------------------------------------------------------------------------------------------
-__device__ inline int sel_pivot_ends(const float* d, int s, int e) {
+__device__ __forceinline__ int sel_pivot_ends(const float* d, int s, int e) {
     const int m = (s + e) / 2;
     if (d[s] < d[e]) return d[m] < d[s] ? s : (d[m] < d[e] ? m : e);
     return d[m] < d[e] ? e : (d[m] < d[s] ? m : s);
@@ -201,41 +201,16 @@ __device__ inline int sel_median_of_medians(float* d, int s, int e) {
         return (groups == 3 || groups == 4) ? sel_med3(d, s) : (groups == 5 ? sel_med5(d, s) : s);
     }
 }
-__device__ inline void dev_intro_select(float* d, int s, int e, int k) {
-    int prev = e - s + 1, tries = 0; bool quick = true; float t;
-    for (;;) {
-        if (s >= e) return;
-        if (e - s <= 5) {
-            for (int i = s + 1; i <= e; i++) for (int j = i; j > s && d[j - 1] > d[j]; j--) { t = d[j - 1]; d[j - 1] = d[j]; d[j] = t; }
-            return;
-        }
-        if (quick && tries++ == 5) { const int len = e - s + 1; if (len * 2 > prev) quick = false; prev = len; tries = 0; }
-        const int pi = quick ? sel_pivot_ends(d, s, e) : sel_median_of_medians(d, s, e);
-        if (pi != s) { t = d[s]; d[s] = d[pi]; d[pi] = t; }
-        const float piv = d[s];
-        int lo = s + 1, hi = e;
-        for (;;) {
-            while (lo < hi && piv >= d[lo]) ++lo;
-            while (lo < hi && piv <= d[hi]) --hi;
-            if (lo >= hi) break;
-            t = d[lo]; d[lo] = d[hi]; d[hi] = t;
-        }
-        const int sp = d[lo] < piv ? lo : lo - 1;
-        d[s] = d[sp]; d[sp] = piv;
-        if (sp < k) s = sp + 1; else if (sp > k) e = sp - 1; else return;
-    }
-}
-
 // Wave-parallel form of the same selection: one wave per residual row. The reference's partition loop pairs the i-th element
 // > pivot from the left with the i-th element < pivot from the right and swaps them while they have not crossed; that final
 // arrangement (and the pivot's resting place) is a pure function of the row, so it is computed with ballots / prefix counts
-// instead of a cell-by-cell scan, and the result is bit-identical to the sequential routine above. `idx` is scratch of n ints.
+// instead of a cell-by-cell scan, and the result is bit-identical to the sequential routine (tests/csrc/partition_check.c). `idx` is scratch of n ints.
 __device__ __forceinline__ void wave_sync_lds() {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
-__device__ inline void wave_intro_select(float* d, int* idx, int n, int k, int lane) {
+__device__ __forceinline__ void wave_intro_select(float* d, int* idx, int n, int k, int lane) {
     int s = 0, e = n - 1;
     int prev = e - s + 1, tries = 0; bool quick = true;
     for (;;) {
