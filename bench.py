@@ -65,7 +65,9 @@ def main():
     import torch
     import torch.distributed as dist
     rank = int(os.environ.get("RANK", "0")); world = int(os.environ.get("WORLD_SIZE", "1")); local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1:
+    # under torch.distributed.run (RANK/MASTER_* set) the collectives are exercised even with one rank
+    use_dist = world > 1 or ("RANK" in os.environ and "MASTER_PORT" in os.environ)
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl")       # RCCL on ROCm
     torch.cuda.set_device(local)
@@ -113,7 +115,7 @@ def main():
         step()
     eng.synchronize()
     ev0 = torch.cuda.Event(enable_timing=True); ev1 = torch.cuda.Event(enable_timing=True)
-    if world > 1:
+    if use_dist:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -124,11 +126,11 @@ def main():
     with torch.cuda.stream(stream):
         ev1.record(stream)
     eng.synchronize(); torch.cuda.synchronize()
-    if world > 1:
+    if use_dist:
         dist.barrier()
     elapsed = time.perf_counter() - t0
     ev_ms = ev0.elapsed_time(ev1)
-    if world > 1:
+    if use_dist:
         tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
@@ -147,10 +149,10 @@ def main():
     if not args.no_register:
         g.clear()
         g.record_jobs(True)
-        if world > 1:
+        if use_dist:
             dist.barrier()
         t0 = time.perf_counter(); out = g.register(); t_reg = time.perf_counter() - t0
-        if world > 1:
+        if use_dist:
             tt = torch.tensor([t_reg], dtype=torch.float64, device=dev); dist.all_reduce(tt, op=dist.ReduceOp.MAX); t_reg_max = float(tt.item())
         else:
             t_reg_max = t_reg
@@ -169,7 +171,7 @@ def main():
         sizes = rngc.integers(150, 401, size=n_pairs * world)
         mine = list(range(rank, n_pairs * world, world))                       # static round-robin shard, no data-path collective
         pairs = [synth_pair(int(sizes[k]), seed=777000 + k, noise=0.01, outlier_frac=0.05, theta_range=(0.3, np.pi), corr_features=True) for k in mine]
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
@@ -191,7 +193,7 @@ def main():
         errs = [o[0] for o in outs_c]; cev = sum(o[1] for o in outs_c)
         t_cav = time.perf_counter() - t0
         rec = torch.tensor([t_cav, float(cev)], dtype=torch.float64, device=dev)
-        if world > 1:
+        if use_dist:
             tmax = rec.clone(); dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
             tsum = rec.clone(); dist.all_reduce(tsum, op=dist.ReduceOp.SUM)
             t_cav = float(tmax[0].item()); cev = int(tsum[1].item())
@@ -241,7 +243,7 @@ def main():
             "cavity_batch": cav,
         }
         print(json.dumps(line))
-    if world > 1:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
 
