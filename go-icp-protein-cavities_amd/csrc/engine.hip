@@ -282,6 +282,7 @@ struct TileShm {
     unsigned prefix[TC];
     int rem[TC];
     unsigned maxb[TC];        // bit pattern of the largest residual per cube
+    unsigned wmax[BLOCK / 64][TC];   // per-wave maxima (plain stores: no initialisation to order against)
     int fallback;
     int zc[TC];               // residuals that are exactly 0 (clamped), counted with ballots instead of LDS adds
     int ncand[TC];            // members of the threshold bin collected for the in-wave refinement
@@ -460,11 +461,12 @@ __device__ __forceinline__ void sweep_tile(const DevTables& T, TileShm<BLOCK>& s
     for (int j = 0; j < NT; j++) { thr[j] = 0u; below[j] = 0; }
     if (T.doTrim && !(T.dbg & 1)) {
         const int wv = tid >> 6, ln = tid & 63;
+        constexpr int NW = BLOCK / 64;
+        // Five workgroup barriers for the whole selection + sums. Everything initialised here is first used after barrier 1.
         for (int k = tid; k < NT * 1024; k += BLOCK) (&sh.hist[0][0])[k] = 0u;
-        if (tid < NT) { sh.prefix[tid] = 0u; sh.rem[tid] = T.inlierNum - 1; sh.maxb[tid] = 0u; sh.zc[tid] = 0; sh.ncand[tid] = 0; }
+        if (tid < NT) { sh.prefix[tid] = 0u; sh.rem[tid] = T.inlierNum - 1; sh.zc[tid] = 0; sh.ncand[tid] = 0; }
         if (tid == 0) sh.fallback = 0;
-        __syncthreads();
-        // (1) largest residual per cube: fixes the 8-octave window of the first pass
+        // (1) largest residual per cube (fixes the 8-octave window of the histogram): per-wave maxima by plain stores
 #pragma unroll
         for (int j = 0; j < NT; j++) {
             unsigned mx = 0u;
@@ -472,29 +474,38 @@ __device__ __forceinline__ void sweep_tile(const DevTables& T, TileShm<BLOCK>& s
             for (int m = 0; m < PPT; m++) if (tid + m * BLOCK < Nd) mx = max(mx, __float_as_uint(r[j][m]));
 #pragma unroll
             for (int off = 32; off > 0; off >>= 1) mx = max(mx, (unsigned)__shfl_down((int)mx, off, 64));
-            if (ln == 0) atomicMax(&sh.maxb[j], mx);
+            if (ln == 0) sh.wmax[wv][j] = mx;
         }
-        __syncthreads();
-        // (2) first pass: 10-bit digit = top 16 bits (sign, exponent, 7 mantissa bits) relative to the cube's maximum:
+        __syncthreads();                                                            // barrier 1
+        int base16[NT];
+#pragma unroll
+        for (int j = 0; j < NT; j++) {
+            unsigned mx = ln < NW ? sh.wmax[ln][j] : 0u;
+#pragma unroll
+            for (int off = 8; off > 0; off >>= 1) mx = max(mx, (unsigned)__shfl_xor((int)mx, off, 64));   // NW <= 16
+            mx = (unsigned)__shfl((int)mx, 0, 64);
+            base16[j] = max(0, (int)(mx >> 16) - 1023);
+            if (tid == j) sh.maxb[j] = mx;
+        }
+        // (2) ONE histogram pass: 10-bit digit = top 16 bits (sign, exponent, 7 mantissa bits) relative to the cube's maximum:
         //     1024 monotone bins over the 8 octaves below the maximum, so the values spread over hundreds of LDS words
         //     instead of piling onto the 2-3 exponent bytes a plain byte pass would see. Residuals clamped to exactly 0
         //     (frequent once a rotation-uncertainty radius is subtracted) are bit-identical and would serialise on one
         //     LDS word, so they are counted with ballots and kept out of the histogram.
 #pragma unroll
         for (int j = 0; j < NT; j++) {
-            const int base16 = max(0, (int)(sh.maxb[j] >> 16) - 1023);
             int z = 0;
 #pragma unroll
             for (int m = 0; m < PPT; m++) {
                 const bool valid = tid + m * BLOCK < Nd;
                 const unsigned bits = __float_as_uint(r[j][m]);
                 z += __popcll(__ballot(valid && bits == 0u));
-                if (valid && bits != 0u) atomicAdd(&sh.hist[j][max(0, (int)(bits >> 16) - base16)], 1u);
+                if (valid && bits != 0u) atomicAdd(&sh.hist[j][max(0, (int)(bits >> 16) - base16[j])], 1u);
             }
             if (ln == 0 && z) atomicAdd(&sh.zc[j], z);
         }
-        __syncthreads();
-        for (int j = wv; j < NT; j += BLOCK / 64) {     // one wave scans the 1024 bins of a cube: 16 per lane
+        __syncthreads();                                                            // barrier 2
+        for (int j = wv; j < NT; j += NW) {             // (3) one wave scans the 1024 bins of a cube: 16 per lane
             unsigned c[16]; int mine = 0;
 #pragma unroll
             for (int q = 0; q < 16; q++) { c[q] = sh.hist[j][16 * ln + q]; mine += (int)c[q]; }
@@ -519,47 +530,79 @@ __device__ __forceinline__ void sweep_tile(const DevTables& T, TileShm<BLOCK>& s
 #pragma unroll
                 for (int q = 1; q < 16; q++) if (b == q) cb = c[q];
                 const int bin = 16 * ln + b;
-                const int base16 = max(0, (int)(sh.maxb[j] >> 16) - 1023);
+                const int b16 = max(0, (int)(sh.maxb[j] >> 16) - 1023);
                 // threshold below the window, or a crowded bin: the generic byte passes decide
-                if ((bin == 0 && base16 > 0) || cb > CAND_CAP) sh.fallback = 1;
-                sh.prefix[j] = (unsigned)(base16 + bin) << 16;
+                if ((bin == 0 && b16 > 0) || cb > CAND_CAP) sh.fallback = 1;
+                sh.prefix[j] = (unsigned)(b16 + bin) << 16;
                 sh.rem[j] = rr;                               // rank among the members of the threshold bin
             }
         }
-        __syncthreads();
+        __syncthreads();                                                            // barrier 3
         if (!sh.fallback) {
-            // (3) collect the members of each threshold bin (a handful) and finish the low 16 bits inside one wave
+            // (4) one pass over the registers: everything below the threshold bin goes into the sums (lane-local float partials
+            //     of <= PPT addends, fp64 across lanes), the bin's members (a handful) into the candidate list
 #pragma unroll
             for (int j = 0; j < NT; j++) {
                 const unsigned p16 = sh.prefix[j] >> 16;
-                if (sh.ncand[j] < 0) continue;                // threshold already known (zero)
+                const bool known = sh.ncand[j] < 0;           // threshold already known (zero): nothing below it
+                const float mtd = sh.mtd[j];
+                float fub = 0.f, flb = 0.f;
 #pragma unroll
                 for (int m = 0; m < PPT; m++) {
-                    const unsigned bits = __float_as_uint(r[j][m]);
-                    if (tid + m * BLOCK < Nd && bits != 0u && (bits >> 16) == p16) {
-                        const int pos = atomicAdd(&sh.ncand[j], 1);
-                        if (pos < CAND_CAP) sh.cand[j][pos] = bits;
-                    }
+                    const float d = r[j][m];
+                    const unsigned bits = __float_as_uint(d);
+                    const bool valid = tid + m * BLOCK < Nd && bits != 0u;      // zeros add nothing to either sum
+                    const unsigned b16 = bits >> 16;
+                    const bool in = valid && b16 < p16;
+                    const float e = d - mtd;
+                    const float tu = T.norm == 2 ? d * d : (T.norm == 1 ? d : 0.f);
+                    const float tl = T.norm == 2 ? e * e : (T.norm == 1 ? e : 0.f);
+                    fub += in ? tu : 0.f;
+                    flb += (in && e > 0.f) ? tl : 0.f;
+                    if (valid && !known && b16 == p16) { const int pos = atomicAdd(&sh.ncand[j], 1); if (pos < CAND_CAP) sh.cand[j][pos] = bits; }
                 }
+                const double u = wave_sum((double)fub), l = wave_sum((double)flb);
+                if (ln == 0) { sh.red[wv][2 * j] = u; sh.red[wv][2 * j + 1] = l; }
             }
-            __syncthreads();
-            for (int j = wv; j < NT; j += BLOCK / 64) {
+            __syncthreads();                                                        // barrier 4
+            // (5) wave j finishes cube j: low 16 bits of the threshold by bisection over the candidates, the candidates below it and
+            //     the copies of the threshold that belong to the inlier set join the partial sums of all waves
+            for (int j = wv; j < NT; j += NW) {
                 const int nc = sh.ncand[j];
-                if (nc < 0) continue;
-                const bool v0 = ln < nc, v1 = ln + 64 < nc;
-                const unsigned c0 = v0 ? sh.cand[j][ln] : 0u, c1 = v1 ? sh.cand[j][ln + 64] : 0u;
-                const int rem = sh.rem[j];
-                unsigned pre = sh.prefix[j];
+                const float mtd = sh.mtd[j];
+                unsigned pre = sh.prefix[j]; int remj = sh.rem[j];
+                double cu = 0.0, cl = 0.0;
+                if (nc >= 0) {
+                    const bool v0 = ln < nc, v1 = ln + 64 < nc;
+                    const unsigned c0 = v0 ? sh.cand[j][ln] : 0u, c1 = v1 ? sh.cand[j][ln + 64] : 0u;
 #pragma unroll
-                for (int b = 15; b >= 0; b--) {
-                    const unsigned cnd = pre | (1u << b);
-                    const int cnt = __popcll(__ballot(v0 && c0 < cnd)) + __popcll(__ballot(v1 && c1 < cnd));
-                    if (cnt <= rem) pre = cnd;                // the rem-th member is >= cnd
+                    for (int b = 15; b >= 0; b--) {
+                        const unsigned cnd = pre | (1u << b);
+                        const int cnt = __popcll(__ballot(v0 && c0 < cnd)) + __popcll(__ballot(v1 && c1 < cnd));
+                        if (cnt <= remj) pre = cnd;               // the rem-th member is >= cnd
+                    }
+                    const int less = __popcll(__ballot(v0 && c0 < pre)) + __popcll(__ballot(v1 && c1 < pre));
+                    remj -= less;                                 // rank among the copies of the threshold
+                    float fu = 0.f, fl = 0.f;
+                    if (v0 && c0 < pre) { const float d = __uint_as_float(c0), e = d - mtd; fu += T.norm == 2 ? d * d : (T.norm == 1 ? d : 0.f); if (e > 0.f) fl += T.norm == 2 ? e * e : (T.norm == 1 ? e : 0.f); }
+                    if (v1 && c1 < pre) { const float d = __uint_as_float(c1), e = d - mtd; fu += T.norm == 2 ? d * d : (T.norm == 1 ? d : 0.f); if (e > 0.f) fl += T.norm == 2 ? e * e : (T.norm == 1 ? e : 0.f); }
+                    cu = (double)fu; cl = (double)fl;
                 }
-                const int less = __popcll(__ballot(v0 && c0 < pre)) + __popcll(__ballot(v1 && c1 < pre));
-                if (ln == 0) { sh.prefix[j] = pre; sh.rem[j] = rem - less; }
+                // partial sums of all waves (lane w holds wave w's), plus this wave's candidate terms
+                cu += ln < NW ? sh.red[ln][2 * j] : 0.0;
+                cl += ln < NW ? sh.red[ln][2 * j + 1] : 0.0;
+                double u = wave_sum(cu), l = wave_sum(cl);
+                if (ln == 0) {
+                    const float d = __uint_as_float(pre);
+                    const float e = d - mtd;
+                    const double n = (double)(remj + 1);          // copies of the threshold inside the inlier set
+                    if (T.norm == 2) { u += n * (double)(d * d); if (e > 0.f) l += n * (double)(e * e); }
+                    else if (T.norm == 1) { u += n * (double)d; if (e > 0.f) l += n * (double)e; }
+                    sh.ub[j] = (float)u; sh.lb[j] = (float)l;
+                }
             }
-            __syncthreads();
+            __syncthreads();                                                        // barrier 5
+            return;
         }
         const bool generic = sh.fallback != 0;
         if (generic) { if (tid < NT) { sh.prefix[tid] = 0u; sh.rem[tid] = T.inlierNum - 1; } }

@@ -1,6 +1,7 @@
 """GPU (-m gpu): boundary behaviour of the C ABI -- empty and ragged inputs, argument errors (status codes, never exits),
 pop budgets, queue-slab regrowth."""
 import ctypes as C
+import os
 
 import numpy as np
 import pytest
@@ -112,3 +113,23 @@ def test_queue_slab_regrowth_gives_the_same_answer(monkeypatch):
         if r["found"]:
             assert np.array_equal(r["node"], H["call_node"][k])
     e.close()
+
+
+def test_bench_prints_the_contract_line():
+    """bench.py --gpus 1: one JSON line with the driver's keys, the roofline and (here skipped) cpu_baseline objects."""
+    import json, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--steps", "2", "--warmup", "1", "--no-cpu", "--no-register"],
+                         capture_output=True, text=True, timeout=180, cwd=root)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    J = json.loads(lines[0])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert k in J, k
+    assert J["n_gpus"] == 1 and J["steps"] == 2 and J["warmup"] == 1 and J["higher_is_better"] is True and J["scaling"] == "weak" and J["vs_baseline"] is None
+    assert J["unit"] == "cube-evals/s" and J["value"] > 1e6 and "workload" in J["config"]
+    R = J["roofline"]
+    assert R["bound"] == "hbm" and R["unit"] == "GB/s" and abs(R["frac"] - R["achieved"] / R["peak"]) < 1e-12 and 0 < R["frac"] < 1
+    # value and the event-timed kernel agree: the step is one launch
+    assert abs(J["ms_per_step"] - R["avg_launch_ms"]) < 0.15 * J["ms_per_step"]
