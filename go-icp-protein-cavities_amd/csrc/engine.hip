@@ -302,7 +302,7 @@ struct TileShm {
 template <int BLOCK, int PPT, bool OCT, int NT>
 __device__ __forceinline__ void sweep_tile(const DevTables& T, TileShm<BLOCK>& sh, const float (&px)[PPT], const float (&py)[PPT],
                                            const float (&pz)[PPT], const float (&pw)[PPT], const float (&prho)[PPT], bool use_rho,
-                                           float* rbuf /* LDS, exact mode only */) {
+                                           float* rbuf /* LDS, exact mode only */, bool row_mode = false /* !OCT: the cubes share y and z */) {
     const int tid = threadIdx.x;
     const int Nd = T.Nd;
     float r[NT][PPT];
@@ -329,7 +329,7 @@ __device__ __forceinline__ void sweep_tile(const DevTables& T, TileShm<BLOCK>& s
                 idx[j] = (unsigned)((clamp_cell(z, S) * S + clamp_cell(y, S)) * S + clamp_cell(x, S));
                 oob |= ((((unsigned)x >= (unsigned)S) | ((unsigned)y >= (unsigned)S) | ((unsigned)z >= (unsigned)S)) ? 1u : 0u) << j;
             }
-        } else if (sh.ctl[2]) {
+        } else if (row_mode) {
             // the 8 cubes form a row (same y and z centre, e.g. 8 x-neighbours of a level grid): the y and z cell
             // arithmetic is shared, 10 axis computations instead of 24
             const int y = cell_of(py[m] + sh.cen[0][1], T.yMin, T.scale), z = cell_of(pz[m] + sh.cen[0][2], T.zMin, T.scale);
@@ -1406,19 +1406,17 @@ __global__ __launch_bounds__(BLOCK) void k_eval_cubes(DevTables T, const float4*
     }
     const bool penalties = T.use_compat || T.use_fpfh;
     __syncthreads();
-    if (tid == 0) {
-        bool row = true;
-        for (int j = 1; j < NT; j++) row = row && sh.cen[j][1] == sh.cen[0][1] && sh.cen[j][2] == sh.cen[0][2];
-        sh.ctl[2] = row ? 1 : 0;
-    }
-    if (penalties && tid < 8 * NT) {
+    // every lane decides for itself whether the tile is a row of x-neighbours (broadcast LDS reads, no second barrier)
+    bool row = true;
+#pragma unroll
+    for (int j = 1; j < NT; j++) row = row && sh.cen[j][1] == sh.cen[0][1] && sh.cen[j][2] == sh.cen[0][2];
+    if (penalties && tid < 8 * NT) {                        // (read by lattice_terms, behind the sweep's barriers)
         const int j = tid >> 3, c = tid & 7;
         sh.lat[tid][0] = sh.cube[j][0] + (c & 1) * sh.cube[j][3];
         sh.lat[tid][1] = sh.cube[j][1] + (c >> 1 & 1) * sh.cube[j][3];
         sh.lat[tid][2] = sh.cube[j][2] + (c >> 2 & 1) * sh.cube[j][3];
     }
-    __syncthreads();
-    sweep_tile<BLOCK, PPT, false, NT>(T, sh, px, py, pz, pw, prho, use_rho, rbuf);
+    sweep_tile<BLOCK, PPT, false, NT>(T, sh, px, py, pz, pw, prho, use_rho, rbuf, row);
     if (penalties) lattice_terms<BLOCK, PPT>(T, sh, 8 * NT, px, py, pz, fpbuf);
     if (tid < NT && base + tid < n) {
         const int j = tid;
