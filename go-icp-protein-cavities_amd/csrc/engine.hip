@@ -912,11 +912,15 @@ __device__ __forceinline__ void sweep_stream(const DevTables& T, TileShm<1024>& 
         su[j] += (double)tu;
         if (e > 0.f) sl[j] += (double)tl;
     };
+    // the next chunk's point is fetched while the current chunk's gathers are in flight
+    float4 pnext = rot[min(tid, Nd - 1)];
+    float rnext = rho_row ? rho_row[min(tid, Nd - 1)] : 0.f;
     for (int b = 0; b < Nd; b += BLOCK) {
         const int i = b + tid;
         const bool valid = i < Nd;
-        const float4 p = rot[valid ? i : Nd - 1];
-        const float rh = rho_row ? rho_row[valid ? i : Nd - 1] : 0.f;
+        const float4 p = pnext;
+        const float rh = rnext;
+        if (b + BLOCK < Nd) { const int in = min(i + BLOCK, Nd - 1); pnext = rot[in]; if (rho_row) rnext = rho_row[in]; }
         unsigned idx[TC]; unsigned oob = 0u;
         if (OCT) {
             int rx[2], ry[2], rz[2];
@@ -1600,7 +1604,9 @@ static void pick_geometry(goicp_engine* h) {
     // lanes x points-per-lane; the residuals of a tile (TC x PPT floats per lane) stay in registers across the
     // selection passes, so large clouds use 512-lane workgroups (256 VGPRs per lane) instead of 1024 (128 VGPRs)
     const int Nd = h->T.Nd;
-    h->streamed = Nd > 8192;
+    // above 5120 points the register-resident geometry would be 512 lanes x 16 points (spills, 66-81 G lookups/s measured);
+    // the streamed sweep does 109-118 G lookups/s there, so geometric runs switch to it early. Penalty runs keep registers up to 8192.
+    h->streamed = Nd > 8192 || (Nd > 5120 && !h->T.use_compat && !h->T.use_fpfh);
     if (h->streamed) { h->block = 1024; h->ppt = 1; }          // cloud streamed from HBM per tile (sweep_stream)
     else if (Nd <= 256) { h->block = 256; h->ppt = 1; }
     else if (Nd <= 512) { h->block = 256; h->ppt = 2; }

@@ -266,11 +266,12 @@ def test_large_cloud_sweep_edge_cases_against_oracle(kind, n):
     e.close()
 
 
+@pytest.mark.parametrize("n", [6000, 12000])
 @pytest.mark.parametrize("trim", [0.0, 0.1])
-def test_streamed_cloud_against_oracle(trim):
-    """Clouds above 8192 points are streamed from HBM (sweep_stream): cube tables, the extension path, the generic byte
-    passes and a bounded InnerBnB against the oracle on a 12 000-point cloud."""
-    n, S = 12000, 60
+def test_streamed_cloud_against_oracle(trim, n):
+    """Geometric runs above 5120 points (any run above 8192) are streamed from HBM (sweep_stream): cube tables, the
+    extension path and a bounded InnerBnB against the oracle on 6 000- and 12 000-point clouds."""
+    S = 60
     P = synth_pair(n, seed=4242)
     v, _ = cfg_vector(distTransSize=S, trimFraction=trim, regularization=0.0, ponderation=0, MSEThresh=0.01)   # loose: keeps the oracle's search short
     o = oracle_for(P, v); o.initialize()
