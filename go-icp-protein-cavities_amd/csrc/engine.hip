@@ -1179,8 +1179,9 @@ __device__ __forceinline__ void sweep_stream(const DevTables& T, TileShm<1024>& 
 // cloud and residuals in registers without spilling.
 // STREAM = true (BLOCK 1024, PPT 1, PEN false): clouds above 8192 points; the rotated cloud lives in the workgroup's slice of
 // T.srot and every pop streams it through sweep_stream instead of holding it in registers.
+// (256-lane geometries: at most 256 registers per lane, so that two searches share a CU)
 template <int BLOCK, int PPT, bool PEN, bool STREAM = false>
-__global__ __launch_bounds__(BLOCK) void k_inner_bnb(DevTables T, const goicp_bnb_job* __restrict__ jobs, goicp_bnb_result* __restrict__ results,
+__global__ __launch_bounds__(BLOCK, (BLOCK == 256 ? 2 : 1)) void k_inner_bnb(DevTables T, const goicp_bnb_job* __restrict__ jobs, goicp_bnb_result* __restrict__ results,
                                                       HeapNode* heaps, int heap_cap, float* fpscratch, unsigned max_pops, int heap_lds_nodes, int rbuf_floats, int fp_lds) {
     __shared__ TileShm<BLOCK> sh;
     __shared__ HeapNode parent;
