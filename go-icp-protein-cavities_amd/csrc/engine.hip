@@ -28,6 +28,7 @@
 #include <vector>
 #include <map>
 #include <algorithm>
+#include <mutex>
 
 #include "goicp_engine.h"
 
@@ -1556,13 +1557,77 @@ struct goicp_engine {
     std::string err;
 };
 
+// ---------------------------------------------------------------------------------------------
+// Device-memory cache. One engine lives for one pair, so a batch creates and destroys engines all the time; hipMalloc and
+// hipFree synchronise the device and serialise the host threads that run registrations side by side. Freed blocks are
+// therefore parked per (device, size class) and handed out again; at most GOICP_CACHE_GB (default 16) gigabytes stay parked.
+// A block is only parked after its engine's stream has been synchronised, so the next owner may use it on any stream.
+// ---------------------------------------------------------------------------------------------
+namespace {
+struct DevCache {
+    std::mutex mu;
+    std::multimap<std::pair<int, size_t>, void*> parked;
+    std::map<void*, std::pair<int, size_t>> live;
+    size_t parked_bytes = 0, limit = 0; bool init = false, off = false;
+    static size_t size_class(size_t n) {
+        if (n <= 256) return 256;
+        if (n < ((size_t)1 << 20)) { size_t p2 = 256; while (p2 < n) p2 <<= 1; return p2; }
+        return (n + ((size_t)2 << 20) - 1) & ~(((size_t)2 << 20) - 1);
+    }
+    void setup() {
+        if (init) return;
+        init = true;
+        const char* e = getenv("GOICP_CACHE_GB");
+        const double gb = e ? atof(e) : 16.0;
+        off = gb <= 0.0; limit = (size_t)(gb * 1073741824.0);
+    }
+};
+DevCache g_cache;
+}  // namespace
+static hipError_t cache_malloc(void** out, size_t bytes, int device) {
+    const size_t cls = DevCache::size_class(bytes);
+    {
+        std::lock_guard<std::mutex> lk(g_cache.mu);
+        g_cache.setup();
+        if (!g_cache.off) {
+            auto it = g_cache.parked.find({device, cls});
+            if (it != g_cache.parked.end()) {
+                *out = it->second; g_cache.parked.erase(it); g_cache.parked_bytes -= cls;
+                g_cache.live[*out] = {device, cls};
+                return hipSuccess;
+            }
+        }
+    }
+    const hipError_t e = hipMalloc(out, cls);
+    if (e == hipSuccess) { std::lock_guard<std::mutex> lk(g_cache.mu); g_cache.live[*out] = {device, cls}; }
+    return e;
+}
+static void cache_free(void* p) {
+    if (!p) return;
+    {
+        std::lock_guard<std::mutex> lk(g_cache.mu);
+        auto it = g_cache.live.find(p);
+        if (it != g_cache.live.end()) {
+            const auto key = it->second;
+            g_cache.live.erase(it);
+            if (!g_cache.off && g_cache.parked_bytes + key.second <= g_cache.limit) { g_cache.parked.emplace(key, p); g_cache.parked_bytes += key.second; return; }
+        }
+    }
+    (void)hipFree(p);
+}
+extern "C" void goicp_engine_release_cached_memory(void) {
+    std::vector<void*> blocks;
+    { std::lock_guard<std::mutex> lk(g_cache.mu); for (auto& kv : g_cache.parked) blocks.push_back(kv.second); g_cache.parked.clear(); g_cache.parked_bytes = 0; }
+    for (void* p : blocks) (void)hipFree(p);
+}
+
 static int fail(goicp_engine* h, int code, const std::string& msg) { if (h) h->err = msg; return code; }
 #define HIPCHK(h, call) do { hipError_t e_ = (call); if (e_ != hipSuccess) return fail(h, GOICP_ERR_HIP, std::string(#call) + ": " + hipGetErrorString(e_)); } while (0)
 
 template <class Tp>
 static int dev_upload(goicp_engine* h, const Tp* src, size_t n, Tp** out) {
     Tp* p = nullptr;
-    HIPCHK(h, hipMalloc((void**)&p, std::max<size_t>(n, 1) * sizeof(Tp)));
+    HIPCHK(h, cache_malloc((void**)&p, std::max<size_t>(n, 1) * sizeof(Tp), h->device));
     h->allocs.push_back(p);
     if (src && n) HIPCHK(h, hipMemcpy(p, src, n * sizeof(Tp), hipMemcpyHostToDevice));
     *out = p;
@@ -1578,12 +1643,13 @@ extern "C" const char* goicp_engine_last_error(const goicp_engine* h) { return h
 extern "C" void goicp_engine_destroy(goicp_engine* h) {
     if (!h) return;
     (void)hipSetDevice(h->device);
-    for (void* p : h->allocs) (void)hipFree(p);
-    if (h->d_heaps) (void)hipFree(h->d_heaps);
-    if (h->d_heap_big) (void)hipFree(h->d_heap_big);
-    if (h->T.srot) (void)hipFree(h->T.srot);
-    if (h->T.srows) (void)hipFree(h->T.srows);
-    if (h->d_fpscratch) (void)hipFree(h->d_fpscratch);
+    if (h->stream) (void)hipStreamSynchronize(h->stream);          // parked blocks must be idle
+    for (void* p : h->allocs) cache_free(p);
+    if (h->d_heaps) cache_free(h->d_heaps);
+    if (h->d_heap_big) cache_free(h->d_heap_big);
+    if (h->T.srot) cache_free(h->T.srot);
+    if (h->T.srows) cache_free(h->T.srows);
+    if (h->d_fpscratch) cache_free(h->d_fpscratch);
     if (h->ev0) (void)hipEventDestroy(h->ev0);
     if (h->ev1) (void)hipEventDestroy(h->ev1);
     if (h->stream) (void)hipStreamDestroy(h->stream);
@@ -1769,7 +1835,7 @@ extern "C" int goicp_engine_create(const goicp_engine_desc* d, goicp_engine** ou
 #undef SETATTR
         if (h->streamed) CRH(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_inner_bnb<1024, 1, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->dyn_lds_bnb));
         {
-            hipDeviceProp_t prop; CRH(hipGetDeviceProperties(&prop, h->device));
+            int ncu = 0; CRH(hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, h->device));   // (a full hipGetDeviceProperties costs ~1 ms per engine)
             int nb = 0;
             const bool pen = T.use_compat || T.use_fpfh;
 #define OCC(B, P) do { if (pen) CRH(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_inner_bnb<B, P, true>, B, h->dyn_lds_bnb)); \
@@ -1777,7 +1843,7 @@ extern "C" int goicp_engine_create(const goicp_engine_desc* d, goicp_engine** ou
             if (h->streamed) CRH(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_inner_bnb<1024, 1, false, true>, 1024, h->dyn_lds_bnb));
             else DISPATCH_GEOM(h, OCC);
 #undef OCC
-            h->resident_jobs = std::max(1, nb) * std::max(1, prop.multiProcessorCount);
+            h->resident_jobs = std::max(1, nb) * std::max(1, ncu);
         }
     }
 #undef CR
@@ -1824,8 +1890,8 @@ extern "C" int goicp_engine_set_rotation(goicp_engine* h, int slot, const float*
 static int ensure_fpscratch(goicp_engine* h, size_t blocks) {
     if (!h->T.use_fpfh) return GOICP_OK;
     if (blocks <= h->fp_blocks) return GOICP_OK;
-    if (h->d_fpscratch) { HIPCHK(h, hipStreamSynchronize(h->stream)); (void)hipFree(h->d_fpscratch); h->d_fpscratch = nullptr; h->fp_blocks = 0; }
-    HIPCHK(h, hipMalloc((void**)&h->d_fpscratch, blocks * NLMAX * (size_t)h->T.Nd * sizeof(float)));
+    if (h->d_fpscratch) { HIPCHK(h, hipStreamSynchronize(h->stream)); cache_free(h->d_fpscratch); h->d_fpscratch = nullptr; h->fp_blocks = 0; }
+    HIPCHK(h, cache_malloc((void**)&h->d_fpscratch, blocks * NLMAX * (size_t)h->T.Nd * sizeof(float), h->device));
     h->fp_blocks = blocks;
     return GOICP_OK;
 }
@@ -1834,12 +1900,12 @@ static int ensure_stream_scratch(goicp_engine* h, size_t wgs, bool need_rot) {
     // per resident workgroup: rotated cloud (search kernel only) + TC residual rows (trimmed runs only)
     if (wgs <= h->stream_wgs) return GOICP_OK;
     HIPCHK(h, hipStreamSynchronize(h->stream));
-    if (h->T.srot) { (void)hipFree(h->T.srot); h->T.srot = nullptr; }
-    if (h->T.srows) { (void)hipFree(h->T.srows); h->T.srows = nullptr; }
+    if (h->T.srot) { cache_free(h->T.srot); h->T.srot = nullptr; }
+    if (h->T.srows) { cache_free(h->T.srows); h->T.srows = nullptr; }
     h->stream_wgs = 0;
     (void)need_rot;
-    HIPCHK(h, hipMalloc((void**)&h->T.srot, wgs * (size_t)h->T.NdP * sizeof(float4)));
-    if (h->T.doTrim) HIPCHK(h, hipMalloc((void**)&h->T.srows, wgs * (size_t)TC * h->T.NdP * sizeof(float)));
+    HIPCHK(h, cache_malloc((void**)&h->T.srot, wgs * (size_t)h->T.NdP * sizeof(float4), h->device));
+    if (h->T.doTrim) HIPCHK(h, cache_malloc((void**)&h->T.srows, wgs * (size_t)TC * h->T.NdP * sizeof(float), h->device));
     h->stream_wgs = wgs;
     return GOICP_OK;
 }
@@ -1933,16 +1999,16 @@ extern "C" int goicp_engine_corner_terms(goicp_engine* h, int slot, const float*
 static int ensure_heaps(goicp_engine* h, size_t jobs) {
     // per-job queue slabs of the batch path (fixed capacity; a job that outgrows its slab is re-run alone on the big slab)
     if (h->d_heaps && jobs <= h->heap_jobs) return GOICP_OK;
-    if (h->d_heaps) { HIPCHK(h, hipStreamSynchronize(h->stream)); (void)hipFree(h->d_heaps); h->d_heaps = nullptr; }
-    HIPCHK(h, hipMalloc((void**)&h->d_heaps, jobs * (size_t)h->heap_cap * sizeof(HeapNode)));
+    if (h->d_heaps) { HIPCHK(h, hipStreamSynchronize(h->stream)); cache_free(h->d_heaps); h->d_heaps = nullptr; }
+    HIPCHK(h, cache_malloc((void**)&h->d_heaps, jobs * (size_t)h->heap_cap * sizeof(HeapNode), h->device));
     h->heap_jobs = jobs;
     return GOICP_OK;
 }
 
 static int ensure_big_heap(goicp_engine* h, int cap) {
     if (h->d_heap_big && cap <= h->heap_big_cap) return GOICP_OK;
-    if (h->d_heap_big) { HIPCHK(h, hipStreamSynchronize(h->stream)); (void)hipFree(h->d_heap_big); h->d_heap_big = nullptr; }
-    HIPCHK(h, hipMalloc((void**)&h->d_heap_big, (size_t)cap * sizeof(HeapNode)));
+    if (h->d_heap_big) { HIPCHK(h, hipStreamSynchronize(h->stream)); cache_free(h->d_heap_big); h->d_heap_big = nullptr; }
+    HIPCHK(h, cache_malloc((void**)&h->d_heap_big, (size_t)cap * sizeof(HeapNode), h->device));
     h->heap_big_cap = cap;
     return GOICP_OK;
 }
@@ -2065,10 +2131,10 @@ extern "C" int goicp_nbr_create(int device_id, const float* xyz, int n, goicp_nb
     if (hipSetDevice(device_id) != hipSuccess) return GOICP_ERR_NO_DEVICE;
     goicp_nbr_ctx* c = new goicp_nbr_ctx();
     c->device = device_id; c->n = n; c->d_xyz = nullptr; c->d_cnt = nullptr;
-    if (hipMalloc((void**)&c->d_xyz, (size_t)3 * n * sizeof(float)) != hipSuccess || hipMalloc((void**)&c->d_cnt, (size_t)n * sizeof(int)) != hipSuccess ||
+    if (cache_malloc((void**)&c->d_xyz, (size_t)3 * n * sizeof(float), device_id) != hipSuccess || cache_malloc((void**)&c->d_cnt, (size_t)n * sizeof(int), device_id) != hipSuccess ||
         hipMemcpy(c->d_xyz, xyz, (size_t)3 * n * sizeof(float), hipMemcpyHostToDevice) != hipSuccess) {
-        if (c->d_xyz) (void)hipFree(c->d_xyz);
-        if (c->d_cnt) (void)hipFree(c->d_cnt);
+        if (c->d_xyz) cache_free(c->d_xyz);
+        if (c->d_cnt) cache_free(c->d_cnt);
         delete c; return GOICP_ERR_HIP;
     }
     *out = c;
@@ -2085,6 +2151,6 @@ extern "C" int goicp_nbr_count(goicp_nbr_ctx* c, double lim, int32_t* counts) {
 extern "C" void goicp_nbr_destroy(goicp_nbr_ctx* c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
-    (void)hipFree(c->d_xyz); (void)hipFree(c->d_cnt);
+    cache_free(c->d_xyz); cache_free(c->d_cnt);
     delete c;
 }

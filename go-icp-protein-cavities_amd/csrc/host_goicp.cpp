@@ -241,6 +241,41 @@ void GoICP::neighborsWeights() {
         if (goicp_nbr_create(device_id, xyz.data(), Nd, &nb) != GOICP_OK) nb = nullptr;
         cnts.resize(Nd);
     }
+    if (!nb && Nd >= 20) {
+        // Host path for cavity-sized clouds. The reference recounts all Nd^2 pairs for every radius step until some point has
+        // 19 neighbours (typically 30-70 steps). Counts only grow with the radius, so: the loop ends at the first step whose
+        // limit exceeds the smallest 19th-nearest distance; the counts it leaves are those of that step; and its running
+        // minimum is the minimum of the FIRST step. Same radius sequence (float accumulation), same distance expression.
+        auto dist_ij = [&](int i, int j) {
+            const double dx = (double)(pData[j].x - pData[i].x), dy = (double)(pData[j].y - pData[i].y), dz = (double)(pData[j].z - pData[i].z);
+            return std::sqrt(dx * dx + dy * dy + dz * dz);
+        };
+        std::vector<double> D((size_t)Nd * Nd), row(Nd);
+        double d19min = 1e300;
+        for (int i = 0; i < Nd; i++) {
+            int m = 0;
+            for (int j = 0; j < Nd; j++) { const double d = dist_ij(i, j); D[(size_t)i * Nd + j] = d; if (j != i) row[m++] = d; }
+            std::nth_element(row.begin(), row.begin() + 18, row.begin() + m);
+            if (row[18] < d19min) d19min = row[18];
+        }
+        auto count_all = [&](double lim, bool track_min) {
+            for (int i = 0; i < Nd; i++) {
+                int cnt = 0;
+                const double* di = &D[(size_t)i * Nd];
+                for (int j = 0; j < Nd; j++) cnt += (j != i && di[j] < lim) ? 1 : 0;
+                pData[i].neighbors = cnt;
+                if (cnt > maxN) maxN = cnt;
+                if (track_min && cnt < minN) minN = cnt;
+            }
+        };
+        for (int step = 0;; step++) {
+            const double lim = (double)std::sqrt(radius);
+            const bool last = d19min < lim;
+            if (step == 0 || last) count_all(lim, step == 0);
+            if (last) break;
+            radius = (float)(radius + 0.001);
+        }
+    }
     while (maxN < 19) {
         if (Nd < 20 && ++guard > 100000) break;      // the reference never terminates for Nd < 20
         const double lim = (double)std::sqrt(radius);

@@ -112,6 +112,9 @@ int goicp_engine_num_slots(const goicp_engine* h);
 /* InnerBnB jobs (one workgroup each) that are resident on the device at once for this engine's geometry: a batch of at most
  * this many jobs runs as one wave of workgroups. The host's speculative batching sizes its launches with it. */
 int goicp_engine_resident_jobs(const goicp_engine* h);
+/* Device memory of destroyed engines is parked per process and reused by the next engine (hipMalloc/hipFree synchronise
+ * the device); this returns the parked blocks to the driver. GOICP_CACHE_GB (default 16, 0 = off) bounds what is parked. */
+void goicp_engine_release_cached_memory(void);
 
 /* (cube) -> (ub, lb) for n cubes given as x,y,z,w quadruples, rotation slot `slot`, rot_level as in the job */
 int goicp_engine_eval_cubes(goicp_engine* h, int slot, int rot_level, const float* cubes, int n, float* ub, float* lb);

@@ -404,6 +404,20 @@ def test_batch_driver_on_one_gpu(tmp_path):
     assert int(allr[0, 14]) == 133 and int(allr[1, 14]) == 118
 
 
+@pytest.mark.parametrize("n", [25, 240, 900])
+def test_neighbour_weights_on_host_match_oracle(n):
+    """ponderation=1 below 1024 points: the host finds the radius step at which the reference's recount loop stops from the
+    19th-nearest distances instead of recounting Nd^2 pairs per step; weights must be bit-equal (incl. duplicate points)."""
+    P = synth_pair(n, seed=1234 + n)
+    s = P["s"].copy(); s[3] = s[2]; s[7] = s[2]                      # exact duplicates: zero distances
+    P = dict(P); P["s"] = s
+    v, _ = cfg_vector(distTransSize=30, ponderation=1, regularization=0.0)
+    o = oracle_for(P, v); o.initialize()
+    g = goicp_amd.GoICP(v); g.set_clouds(P["t"], P["s"]); g.build_dt(); g.initialize()
+    assert np.array_equal(g.weights(), o.weights())
+    g.close()
+
+
 def test_neighbour_weights_on_device_match_oracle():
     """ponderation=1 on a 3000-point cloud: the O(Nd^2) neighbour counts run on the device (Nd >= 1024); weights must be bit-equal."""
     P = synth_pair(3000, seed=99)
