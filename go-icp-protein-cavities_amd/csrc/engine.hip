@@ -1569,6 +1569,8 @@ struct DevCache {
     std::multimap<std::pair<int, size_t>, void*> parked;
     std::map<void*, std::pair<int, size_t>> live;
     size_t parked_bytes = 0, limit = 0; bool init = false, off = false;
+    struct Queue { int device; hipStream_t stream; hipEvent_t ev0, ev1; };
+    std::vector<Queue> queues;                 // idle (stream, event, event) triples of destroyed engines
     static size_t size_class(size_t n) {
         if (n <= 256) return 256;
         if (n < ((size_t)1 << 20)) { size_t p2 = 256; while (p2 < n) p2 <<= 1; return p2; }
@@ -1615,10 +1617,36 @@ static void cache_free(void* p) {
     }
     (void)hipFree(p);
 }
+static hipError_t cache_queue(int device, hipStream_t* st, hipEvent_t* e0, hipEvent_t* e1) {
+    {
+        std::lock_guard<std::mutex> lk(g_cache.mu);
+        g_cache.setup();
+        for (size_t k = 0; k < g_cache.queues.size(); k++) if (g_cache.queues[k].device == device) {
+            *st = g_cache.queues[k].stream; *e0 = g_cache.queues[k].ev0; *e1 = g_cache.queues[k].ev1;
+            g_cache.queues.erase(g_cache.queues.begin() + k);
+            return hipSuccess;
+        }
+    }
+    hipError_t e = hipStreamCreate(st);
+    if (e == hipSuccess) e = hipEventCreate(e0);
+    if (e == hipSuccess) e = hipEventCreate(e1);
+    return e;
+}
+static void cache_queue_return(int device, hipStream_t st, hipEvent_t e0, hipEvent_t e1) {
+    if (st && e0 && e1) {
+        std::lock_guard<std::mutex> lk(g_cache.mu);
+        if (!g_cache.off && g_cache.queues.size() < 64) { g_cache.queues.push_back({device, st, e0, e1}); return; }
+    }
+    if (e0) (void)hipEventDestroy(e0);
+    if (e1) (void)hipEventDestroy(e1);
+    if (st) (void)hipStreamDestroy(st);
+}
 extern "C" void goicp_engine_release_cached_memory(void) {
     std::vector<void*> blocks;
-    { std::lock_guard<std::mutex> lk(g_cache.mu); for (auto& kv : g_cache.parked) blocks.push_back(kv.second); g_cache.parked.clear(); g_cache.parked_bytes = 0; }
+    std::vector<DevCache::Queue> qs;
+    { std::lock_guard<std::mutex> lk(g_cache.mu); for (auto& kv : g_cache.parked) blocks.push_back(kv.second); g_cache.parked.clear(); g_cache.parked_bytes = 0; qs.swap(g_cache.queues); }
     for (void* p : blocks) (void)hipFree(p);
+    for (auto& q : qs) { (void)hipEventDestroy(q.ev0); (void)hipEventDestroy(q.ev1); (void)hipStreamDestroy(q.stream); }
 }
 
 static int fail(goicp_engine* h, int code, const std::string& msg) { if (h) h->err = msg; return code; }
@@ -1650,9 +1678,7 @@ extern "C" void goicp_engine_destroy(goicp_engine* h) {
     if (h->T.srot) cache_free(h->T.srot);
     if (h->T.srows) cache_free(h->T.srows);
     if (h->d_fpscratch) cache_free(h->d_fpscratch);
-    if (h->ev0) (void)hipEventDestroy(h->ev0);
-    if (h->ev1) (void)hipEventDestroy(h->ev1);
-    if (h->stream) (void)hipStreamDestroy(h->stream);
+    cache_queue_return(h->device, h->stream, h->ev0, h->ev1);   // (already synchronised above)
     delete h;
 }
 
@@ -1717,9 +1743,7 @@ extern "C" int goicp_engine_create(const goicp_engine_desc* d, goicp_engine** ou
 #define CR(call) do { int rc_ = (call); if (rc_ != GOICP_OK) { std::string m = h->err; goicp_engine_destroy(h); fprintf(stderr, "goicp_engine_create: %s\n", m.c_str()); return rc_; } } while (0)
 #define CRH(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { fprintf(stderr, "goicp_engine_create: %s: %s\n", #call, hipGetErrorString(e_)); goicp_engine_destroy(h); return GOICP_ERR_NO_DEVICE; } } while (0)
     CRH(hipSetDevice(h->device));
-    CRH(hipStreamCreate(&h->stream));
-    CRH(hipEventCreate(&h->ev0));
-    CRH(hipEventCreate(&h->ev1));
+    CRH(cache_queue(h->device, &h->stream, &h->ev0, &h->ev1));
     DevTables& T = h->T;
     T.S = d->S; T.xMin = d->xMin; T.yMin = d->yMin; T.zMin = d->zMin; T.scale = d->scale;
     T.Nd = d->Nd; T.Nm = d->Nm; T.doTrim = d->doTrim ? 1 : 0; T.inlierNum = d->doTrim ? d->inlierNum : d->Nd; T.norm = d->norm;
