@@ -1510,8 +1510,10 @@ __global__ void k_point_eval(DevTables T, const double* __restrict__ Rt /*R[9], 
 // (jly_icp3d.hpp:54-60). One wave per query point: lane l scans model points l, l+64, ... (strict '<' keeps the
 // first, i.e. lowest, index of its stride), then the wave reduces on (distance, index) so that the lowest model
 // index wins among exact ties.
-__global__ __launch_bounds__(256) void k_icp_nn(DevTables T, const float* __restrict__ mxyz, const float* __restrict__ Rt /*float R[9], t[3]*/,
+struct RtArg { float v[12]; };                    // float R[9], t[3], passed by value (no staging copy per ICP iteration)
+__global__ __launch_bounds__(256) void k_icp_nn(DevTables T, const float* __restrict__ mxyz, RtArg rt,
                                                  int* __restrict__ id_out, float* __restrict__ d_out) {
+    const float* Rt = rt.v;
     const int lane = threadIdx.x & 63;
     const int i = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     if (i >= T.Nd) return;                         // whole waves leave together
@@ -1539,6 +1541,7 @@ __global__ __launch_bounds__(256) void k_icp_nn(DevTables T, const float* __rest
 struct goicp_engine {
     int device;
     hipStream_t stream;
+    void* pinned;                             // PINNED_BYTES of host memory (may be null), travels with the stream in the pool
     hipEvent_t ev0, ev1;
     DevTables T;
     std::vector<void*> allocs;
@@ -1569,7 +1572,7 @@ struct DevCache {
     std::multimap<std::pair<int, size_t>, void*> parked;
     std::map<void*, std::pair<int, size_t>> live;
     size_t parked_bytes = 0, limit = 0; bool init = false, off = false;
-    struct Queue { int device; hipStream_t stream; hipEvent_t ev0, ev1; };
+    struct Queue { int device; hipStream_t stream; hipEvent_t ev0, ev1; void* pinned; };   // pinned: PINNED_BYTES of host memory the device writes results into
     std::vector<Queue> queues;                 // idle (stream, event, event) triples of destroyed engines
     static size_t size_class(size_t n) {
         if (n <= 256) return 256;
@@ -1617,12 +1620,13 @@ static void cache_free(void* p) {
     }
     (void)hipFree(p);
 }
-static hipError_t cache_queue(int device, hipStream_t* st, hipEvent_t* e0, hipEvent_t* e1) {
+#define PINNED_BYTES ((size_t)1 << 20)
+static hipError_t cache_queue(int device, hipStream_t* st, hipEvent_t* e0, hipEvent_t* e1, void** pinned) {
     {
         std::lock_guard<std::mutex> lk(g_cache.mu);
         g_cache.setup();
         for (size_t k = 0; k < g_cache.queues.size(); k++) if (g_cache.queues[k].device == device) {
-            *st = g_cache.queues[k].stream; *e0 = g_cache.queues[k].ev0; *e1 = g_cache.queues[k].ev1;
+            *st = g_cache.queues[k].stream; *e0 = g_cache.queues[k].ev0; *e1 = g_cache.queues[k].ev1; *pinned = g_cache.queues[k].pinned;
             g_cache.queues.erase(g_cache.queues.begin() + k);
             return hipSuccess;
         }
@@ -1630,23 +1634,25 @@ static hipError_t cache_queue(int device, hipStream_t* st, hipEvent_t* e0, hipEv
     hipError_t e = hipStreamCreate(st);
     if (e == hipSuccess) e = hipEventCreate(e0);
     if (e == hipSuccess) e = hipEventCreate(e1);
+    if (e == hipSuccess && hipHostMalloc(pinned, PINNED_BYTES) != hipSuccess) *pinned = nullptr;   // optional: callers fall back to copies
     return e;
 }
-static void cache_queue_return(int device, hipStream_t st, hipEvent_t e0, hipEvent_t e1) {
+static void cache_queue_return(int device, hipStream_t st, hipEvent_t e0, hipEvent_t e1, void* pinned) {
     if (st && e0 && e1) {
         std::lock_guard<std::mutex> lk(g_cache.mu);
-        if (!g_cache.off && g_cache.queues.size() < 64) { g_cache.queues.push_back({device, st, e0, e1}); return; }
+        if (!g_cache.off && g_cache.queues.size() < 64) { g_cache.queues.push_back({device, st, e0, e1, pinned}); return; }
     }
     if (e0) (void)hipEventDestroy(e0);
     if (e1) (void)hipEventDestroy(e1);
     if (st) (void)hipStreamDestroy(st);
+    if (pinned) (void)hipHostFree(pinned);
 }
 extern "C" void goicp_engine_release_cached_memory(void) {
     std::vector<void*> blocks;
     std::vector<DevCache::Queue> qs;
     { std::lock_guard<std::mutex> lk(g_cache.mu); for (auto& kv : g_cache.parked) blocks.push_back(kv.second); g_cache.parked.clear(); g_cache.parked_bytes = 0; qs.swap(g_cache.queues); }
     for (void* p : blocks) (void)hipFree(p);
-    for (auto& q : qs) { (void)hipEventDestroy(q.ev0); (void)hipEventDestroy(q.ev1); (void)hipStreamDestroy(q.stream); }
+    for (auto& q : qs) { (void)hipEventDestroy(q.ev0); (void)hipEventDestroy(q.ev1); (void)hipStreamDestroy(q.stream); if (q.pinned) (void)hipHostFree(q.pinned); }
 }
 
 static int fail(goicp_engine* h, int code, const std::string& msg) { if (h) h->err = msg; return code; }
@@ -1678,7 +1684,7 @@ extern "C" void goicp_engine_destroy(goicp_engine* h) {
     if (h->T.srot) cache_free(h->T.srot);
     if (h->T.srows) cache_free(h->T.srows);
     if (h->d_fpscratch) cache_free(h->d_fpscratch);
-    cache_queue_return(h->device, h->stream, h->ev0, h->ev1);   // (already synchronised above)
+    cache_queue_return(h->device, h->stream, h->ev0, h->ev1, h->pinned);   // (already synchronised above)
     delete h;
 }
 
@@ -1737,13 +1743,13 @@ extern "C" int goicp_engine_create(const goicp_engine_desc* d, goicp_engine** ou
     goicp_engine* h = new goicp_engine();
     memset(&h->T, 0, sizeof h->T);
     h->device = d->device_id; h->stream = nullptr; h->ev0 = h->ev1 = nullptr;
-    h->streamed = 0; h->stream_wgs = 0;
+    h->streamed = 0; h->stream_wgs = 0; h->pinned = nullptr;
     h->d_heaps = nullptr; h->d_fpscratch = nullptr; h->heap_cap = 8192; h->heap_jobs = 0; h->fp_blocks = 0; h->d_heap_big = nullptr; h->heap_big_cap = 0;
     h->n_cubes = h->n_lookups = 0; h->kernel_ms = 0; h->max_pops = 200000000u;
 #define CR(call) do { int rc_ = (call); if (rc_ != GOICP_OK) { std::string m = h->err; goicp_engine_destroy(h); fprintf(stderr, "goicp_engine_create: %s\n", m.c_str()); return rc_; } } while (0)
 #define CRH(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { fprintf(stderr, "goicp_engine_create: %s: %s\n", #call, hipGetErrorString(e_)); goicp_engine_destroy(h); return GOICP_ERR_NO_DEVICE; } } while (0)
     CRH(hipSetDevice(h->device));
-    CRH(cache_queue(h->device, &h->stream, &h->ev0, &h->ev1));
+    CRH(cache_queue(h->device, &h->stream, &h->ev0, &h->ev1, &h->pinned));
     DevTables& T = h->T;
     T.S = d->S; T.xMin = d->xMin; T.yMin = d->yMin; T.zMin = d->zMin; T.scale = d->scale;
     T.Nd = d->Nd; T.Nm = d->Nm; T.doTrim = d->doTrim ? 1 : 0; T.inlierNum = d->doTrim ? d->inlierNum : d->Nd; T.norm = d->norm;
@@ -2108,11 +2114,21 @@ extern "C" int goicp_engine_point_eval(goicp_engine* h, const double* R9, const 
 extern "C" int goicp_engine_icp_nn(goicp_engine* h, const double* R9, const double* t3, int32_t* id_model, float* dist_sq) {
     if (!h || !R9 || !t3 || !id_model || !dist_sq || h->T.Nm <= 0) return GOICP_ERR_ARG;
     HIPCHK(h, hipSetDevice(h->device));
-    float Rt[12];
-    for (int k = 0; k < 9; k++) Rt[k] = (float)R9[k];
-    for (int k = 0; k < 3; k++) Rt[9 + k] = (float)t3[k];
-    HIPCHK(h, hipMemcpyAsync(h->d_Rtf, Rt, sizeof Rt, hipMemcpyHostToDevice, h->stream));
-    hipLaunchKernelGGL(k_icp_nn, dim3((h->T.Nd + 3) / 4), dim3(256), 0, h->stream, h->T, h->d_mxyz, h->d_Rtf, h->d_int, h->d_dist);
+    RtArg rt;
+    for (int k = 0; k < 9; k++) rt.v[k] = (float)R9[k];
+    for (int k = 0; k < 3; k++) rt.v[9 + k] = (float)t3[k];
+    const size_t Nd = (size_t)h->T.Nd;
+    if (h->pinned && Nd * 8 <= PINNED_BYTES) {
+        // small clouds (every ICP iteration of a cavity pair comes through here): the kernel writes its two result arrays
+        // straight into pinned host memory, so an iteration is one launch and one stream synchronisation
+        int* pid = (int*)h->pinned; float* pd = (float*)h->pinned + Nd;
+        hipLaunchKernelGGL(k_icp_nn, dim3((h->T.Nd + 3) / 4), dim3(256), 0, h->stream, h->T, h->d_mxyz, rt, pid, pd);
+        HIPCHK(h, hipGetLastError());
+        HIPCHK(h, hipStreamSynchronize(h->stream));
+        memcpy(id_model, pid, Nd * sizeof(int)); memcpy(dist_sq, pd, Nd * sizeof(float));
+        return GOICP_OK;
+    }
+    hipLaunchKernelGGL(k_icp_nn, dim3((h->T.Nd + 3) / 4), dim3(256), 0, h->stream, h->T, h->d_mxyz, rt, h->d_int, h->d_dist);
     HIPCHK(h, hipGetLastError());
     HIPCHK(h, hipMemcpyAsync(id_model, h->d_int, (size_t)h->T.Nd * sizeof(int), hipMemcpyDeviceToHost, h->stream));
     HIPCHK(h, hipMemcpyAsync(dist_sq, h->d_dist, (size_t)h->T.Nd * sizeof(float), hipMemcpyDeviceToHost, h->stream));
