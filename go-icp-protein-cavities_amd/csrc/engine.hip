@@ -1491,7 +1491,9 @@ __global__ void k_rotate(DevTables T, const float* __restrict__ R, float4* __res
 }
 
 // (float)(R*p + t) with double R,t (reference jly_goicp.cpp:120-122, 937-939), DT lookup, compat flag
-__global__ void k_point_eval(DevTables T, const double* __restrict__ Rt /*R[9], t[3]*/, float* __restrict__ dist, int* __restrict__ compat) {
+struct RtArgD { double v[12]; };                 // double R[9], t[3] by value
+__global__ void k_point_eval(DevTables T, RtArgD rt, float* __restrict__ dist, int* __restrict__ compat) {
+    const double* Rt = rt.v;
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= T.Nd) return;
     const float px = T.dxyz[3 * i], py = T.dxyz[3 * i + 1], pz = T.dxyz[3 * i + 2];
@@ -1551,7 +1553,7 @@ struct goicp_engine {
     HeapNode* d_heaps; int heap_cap; size_t heap_jobs; HeapNode* d_heap_big; int heap_big_cap;
     float* d_fpscratch; size_t fp_blocks;
     float* d_cubes; float* d_ub; float* d_lb; int cube_cap; int2* d_groups; std::vector<int2> groups_host;
-    double* d_Rt; float* d_Rtf; float* d_dist; int* d_int; float* d_lat; int lat_cap; int* d_cnt; float* d_fp;
+    float* d_dist; int* d_int; float* d_lat; int lat_cap; int* d_cnt; float* d_fp;
     int block, ppt; size_t dyn_lds; size_t dyn_lds_bnb; int heap_lds_nodes; int rbuf_floats; int fp_lds;
     int resident_jobs;                       // search workgroups resident at once (CUs x occupancy of the chosen k_inner_bnb)
     int streamed; size_t stream_wgs;        // streaming path (Nd > 8192): scratch sized for this many resident workgroups
@@ -1845,8 +1847,6 @@ extern "C" int goicp_engine_create(const goicp_engine_desc* d, goicp_engine** ou
     CR(dev_upload<float>(h, nullptr, (size_t)4 * h->cube_cap, &h->d_cubes));
     CR(dev_upload<float>(h, nullptr, h->cube_cap, &h->d_ub));
     CR(dev_upload<float>(h, nullptr, h->cube_cap, &h->d_lb));
-    CR(dev_upload<double>(h, nullptr, 12, &h->d_Rt));
-    CR(dev_upload<float>(h, nullptr, 12, &h->d_Rtf));
     CR(dev_upload<float>(h, nullptr, d->Nd, &h->d_dist));
     CR(dev_upload<int>(h, nullptr, d->Nd, &h->d_int));
     h->lat_cap = 1 << 14;
@@ -2047,17 +2047,25 @@ static int run_bnb(goicp_engine* h, const goicp_bnb_job* jobs, int njobs, goicp_
     int rc = ensure_fpscratch(h, (size_t)njobs);
     if (rc != GOICP_OK) return rc;
     if (h->streamed) { rc = ensure_stream_scratch(h, (size_t)njobs, true); if (rc != GOICP_OK) return rc; }
-    HIPCHK(h, hipMemcpyAsync(h->d_jobs, jobs, (size_t)njobs * sizeof(goicp_bnb_job), hipMemcpyHostToDevice, h->stream));
+    // job descriptors and results go through the pooled pinned buffer when they fit: the kernel reads its job and writes its
+    // result over the bus, so a launch costs no staging copies
+    const bool zero_copy = h->pinned && (size_t)njobs * (sizeof(goicp_bnb_job) + sizeof(goicp_bnb_result)) <= PINNED_BYTES;
+    goicp_bnb_job* k_jobs = h->d_jobs; goicp_bnb_result* k_results = h->d_results;
+    if (zero_copy) {
+        k_jobs = (goicp_bnb_job*)h->pinned; k_results = (goicp_bnb_result*)(k_jobs + njobs);
+        memcpy(k_jobs, jobs, (size_t)njobs * sizeof(goicp_bnb_job));
+    } else HIPCHK(h, hipMemcpyAsync(h->d_jobs, jobs, (size_t)njobs * sizeof(goicp_bnb_job), hipMemcpyHostToDevice, h->stream));
     HIPCHK(h, hipEventRecord(h->ev0, h->stream));
-#define CALL(B, P) do { if (h->T.use_compat || h->T.use_fpfh) hipLaunchKernelGGL((k_inner_bnb<B, P, true>), dim3(njobs), dim3(B), h->dyn_lds_bnb, h->stream, h->T, h->d_jobs, h->d_results, heaps, cap, h->d_fpscratch, h->max_pops, h->heap_lds_nodes, h->rbuf_floats, h->fp_lds); \
-                        else hipLaunchKernelGGL((k_inner_bnb<B, P, false>), dim3(njobs), dim3(B), h->dyn_lds_bnb, h->stream, h->T, h->d_jobs, h->d_results, heaps, cap, h->d_fpscratch, h->max_pops, h->heap_lds_nodes, h->rbuf_floats, h->fp_lds); } while (0)
-    if (h->streamed) hipLaunchKernelGGL((k_inner_bnb<1024, 1, false, true>), dim3(njobs), dim3(1024), h->dyn_lds_bnb, h->stream, h->T, h->d_jobs, h->d_results, heaps, cap, h->d_fpscratch, h->max_pops, h->heap_lds_nodes, h->rbuf_floats, h->fp_lds);
+#define CALL(B, P) do { if (h->T.use_compat || h->T.use_fpfh) hipLaunchKernelGGL((k_inner_bnb<B, P, true>), dim3(njobs), dim3(B), h->dyn_lds_bnb, h->stream, h->T, k_jobs, k_results, heaps, cap, h->d_fpscratch, h->max_pops, h->heap_lds_nodes, h->rbuf_floats, h->fp_lds); \
+                        else hipLaunchKernelGGL((k_inner_bnb<B, P, false>), dim3(njobs), dim3(B), h->dyn_lds_bnb, h->stream, h->T, k_jobs, k_results, heaps, cap, h->d_fpscratch, h->max_pops, h->heap_lds_nodes, h->rbuf_floats, h->fp_lds); } while (0)
+    if (h->streamed) hipLaunchKernelGGL((k_inner_bnb<1024, 1, false, true>), dim3(njobs), dim3(1024), h->dyn_lds_bnb, h->stream, h->T, k_jobs, k_results, heaps, cap, h->d_fpscratch, h->max_pops, h->heap_lds_nodes, h->rbuf_floats, h->fp_lds);
     else DISPATCH_GEOM(h, CALL);
 #undef CALL
     HIPCHK(h, hipGetLastError());
     HIPCHK(h, hipEventRecord(h->ev1, h->stream));
-    HIPCHK(h, hipMemcpyAsync(results, h->d_results, (size_t)njobs * sizeof(goicp_bnb_result), hipMemcpyDeviceToHost, h->stream));
+    if (!zero_copy) HIPCHK(h, hipMemcpyAsync(results, h->d_results, (size_t)njobs * sizeof(goicp_bnb_result), hipMemcpyDeviceToHost, h->stream));
     HIPCHK(h, hipStreamSynchronize(h->stream));
+    if (zero_copy) memcpy(results, k_results, (size_t)njobs * sizeof(goicp_bnb_result));
     float ms = 0.f; (void)hipEventElapsedTime(&ms, h->ev0, h->ev1); h->kernel_ms += ms;
     return GOICP_OK;
 }
@@ -2100,13 +2108,22 @@ extern "C" int goicp_engine_inner_bnb(goicp_engine* h, const goicp_bnb_job* job,
 extern "C" int goicp_engine_point_eval(goicp_engine* h, const double* R9, const double* t3, float* dist, int32_t* compat) {
     if (!h || !R9 || !t3 || !dist) return GOICP_ERR_ARG;
     HIPCHK(h, hipSetDevice(h->device));
-    double Rt[12]; memcpy(Rt, R9, 9 * sizeof(double)); memcpy(Rt + 9, t3, 3 * sizeof(double));
-    HIPCHK(h, hipMemcpyAsync(h->d_Rt, Rt, sizeof Rt, hipMemcpyHostToDevice, h->stream));
-    hipLaunchKernelGGL(k_point_eval, dim3((h->T.Nd + 255) / 256), dim3(256), 0, h->stream, h->T, h->d_Rt, h->d_dist, compat ? h->d_int : nullptr);
-    HIPCHK(h, hipGetLastError());
-    HIPCHK(h, hipMemcpyAsync(dist, h->d_dist, (size_t)h->T.Nd * sizeof(float), hipMemcpyDeviceToHost, h->stream));
-    if (compat) HIPCHK(h, hipMemcpyAsync(compat, h->d_int, (size_t)h->T.Nd * sizeof(int), hipMemcpyDeviceToHost, h->stream));
-    HIPCHK(h, hipStreamSynchronize(h->stream));
+    RtArgD rt; memcpy(rt.v, R9, 9 * sizeof(double)); memcpy(rt.v + 9, t3, 3 * sizeof(double));
+    const size_t Nd = (size_t)h->T.Nd;
+    if (h->pinned && Nd * 8 <= PINNED_BYTES) {
+        float* pd = (float*)h->pinned; int* pc = (int*)h->pinned + Nd;
+        hipLaunchKernelGGL(k_point_eval, dim3((h->T.Nd + 255) / 256), dim3(256), 0, h->stream, h->T, rt, pd, compat ? pc : nullptr);
+        HIPCHK(h, hipGetLastError());
+        HIPCHK(h, hipStreamSynchronize(h->stream));
+        memcpy(dist, pd, Nd * sizeof(float));
+        if (compat) memcpy(compat, pc, Nd * sizeof(int));
+    } else {
+        hipLaunchKernelGGL(k_point_eval, dim3((h->T.Nd + 255) / 256), dim3(256), 0, h->stream, h->T, rt, h->d_dist, compat ? h->d_int : nullptr);
+        HIPCHK(h, hipGetLastError());
+        HIPCHK(h, hipMemcpyAsync(dist, h->d_dist, (size_t)h->T.Nd * sizeof(float), hipMemcpyDeviceToHost, h->stream));
+        if (compat) HIPCHK(h, hipMemcpyAsync(compat, h->d_int, (size_t)h->T.Nd * sizeof(int), hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(h, hipStreamSynchronize(h->stream));
+    }
     h->n_lookups += (uint64_t)h->T.Nd;
     return GOICP_OK;
 }
