@@ -63,6 +63,9 @@ static void fill(std::vector<POINT3D>& v, int n, const float* xyz, const int32_t
 int goicp_set_clouds(goicp_handle* h, int Nm, const float* mxyz, const int32_t* mcol, const float* mfpfh,
                      int Nd, const float* dxyz, const int32_t* dcol, const float* dfpfh) {
     if (!h || Nm <= 0 || Nd <= 0 || !mxyz || !dxyz) return GOICP_ERR_ARG;
+    // non-finite coordinates walk the reference's selection and sorting loops out of their arrays; refuse them here
+    for (size_t k = 0; k < (size_t)3 * Nm; k++) if (!std::isfinite(mxyz[k])) { h->g.status = GOICP_ERR_ARG; h->g.error_message = "model cloud holds a non-finite coordinate"; return GOICP_ERR_ARG; }
+    for (size_t k = 0; k < (size_t)3 * Nd; k++) if (!std::isfinite(dxyz[k])) { h->g.status = GOICP_ERR_ARG; h->g.error_message = "data cloud holds a non-finite coordinate"; return GOICP_ERR_ARG; }
     fill(h->model, Nm, mxyz, mcol, mfpfh); fill(h->data, Nd, dxyz, dcol, dfpfh);
     h->g.pModel = h->model.data(); h->g.Nm = Nm; h->g.pData = h->data.data(); h->g.Nd = Nd;
     return GOICP_OK;

@@ -210,6 +210,9 @@ void GoICP::log_error(const char* tag, float v) {
 
 // reference jly_goicp.cpp:79-99 + assignCellColor (:951-969)
 void GoICP::BuildDT() {
+    for (int i = 0; i < Nm; i++) if (!std::isfinite(pModel[i].x) || !std::isfinite(pModel[i].y) || !std::isfinite(pModel[i].z)) {
+        status = GOICP_ERR_ARG; error_message = "model cloud holds a non-finite coordinate"; return;
+    }
     std::vector<double> x(Nm), y(Nm), z(Nm);
     for (int i = 0; i < Nm; i++) { x[i] = pModel[i].x; y[i] = pModel[i].y; z[i] = pModel[i].z; }
     dt.Build(x.data(), y.data(), z.data(), Nm);
@@ -708,6 +711,13 @@ float GoICP::Register() {
     trace.clear(); stats = RegisterStats(); job_log.clear(); result_log.clear(); icp_ms_ = 0;
     const bool timing = getenv("GOICP_TIMING") != nullptr;
     const double t0 = now_ms();
+    // non-finite coordinates would walk the (reference-order) selection and sorting loops out of their arrays: refuse them
+    for (int i = 0; i < Nd; i++) if (!std::isfinite(pData[i].x) || !std::isfinite(pData[i].y) || !std::isfinite(pData[i].z)) {
+        status = GOICP_ERR_ARG; error_message = "data cloud holds a non-finite coordinate"; return std::numeric_limits<float>::quiet_NaN();
+    }
+    for (int i = 0; i < Nm; i++) if (!std::isfinite(pModel[i].x) || !std::isfinite(pModel[i].y) || !std::isfinite(pModel[i].z)) {
+        status = GOICP_ERR_ARG; error_message = "model cloud holds a non-finite coordinate"; return std::numeric_limits<float>::quiet_NaN();
+    }
     Initialize();
     const double t1 = now_ms();
     if (!eng_) return std::numeric_limits<float>::quiet_NaN();

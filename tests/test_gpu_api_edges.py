@@ -133,3 +133,24 @@ def test_bench_prints_the_contract_line():
     assert R["bound"] == "hbm" and R["unit"] == "GB/s" and abs(R["frac"] - R["achieved"] / R["peak"]) < 1e-12 and 0 < R["frac"] < 1
     # value and the event-timed kernel agree: the step is one launch
     assert abs(J["ms_per_step"] - R["avg_launch_ms"]) < 0.15 * J["ms_per_step"]
+
+
+def test_non_finite_coordinates_are_refused_and_tiny_clouds_register():
+    """NaN / inf coordinates come back as an error from set_clouds (they would walk the reference-order selection loops out
+    of their arrays); degenerate but finite inputs (one point, identical points, a 2^3 grid, far outside the grid) register."""
+    from goicp_amd.synth import synth_pair
+    P = synth_pair(200, seed=5)
+    geo = dict(ponderation=0, regularization=0.0)
+    for bad in (np.nan, np.inf):
+        s = P["s"].copy(); s[3, 1] = bad
+        g = goicp_amd.GoICP(goicp_amd.cfg_vector(**geo))
+        with pytest.raises(goicp_amd.EngineError):
+            g.set_clouds(P["t"], s)
+        g.close()
+    for t, s, cfg in ((P["t"], P["s"][:1], geo), (P["t"], np.repeat(P["s"][:1], 50, 0), geo), (P["t"], P["s"], dict(geo, distTransSize=2)),
+                      (P["t"][:1], P["s"], geo), (P["t"], P["s"] * 50, dict(geo, MSEThresh=10.0)), (P["t"], P["s"], dict(geo, trimFraction=0.99)),
+                      (P["t"], P["s"][:5], dict(regularization=0.0))):
+        g = goicp_amd.GoICP(goicp_amd.cfg_vector(**cfg)); g.set_clouds(t, s); g.build_dt()
+        out = g.register()
+        assert np.isfinite(out["error"]) and np.all(np.isfinite(out["R"])) and np.all(np.isfinite(out["t"]))
+        g.close()
