@@ -225,8 +225,8 @@ def main():
         default_shape = nd == N_POINTS and args.dt == DT_SIZE and abs(args.trim - TRIM) < 1e-9
         if not default_shape:
             traffic = None                      # the committed PMC summary belongs to the default shape only
-        geom = [(256, 1, 256), (512, 2, 256), (1024, 1, 1024), (2048, 2, 1024), (4096, 4, 1024), (5120, 5, 1024)]
-        kname = next(("k_eval_cubes<%d,%d,8>" % (b, p) for lim, p, b in geom if nd <= lim), "k_eval_cubes_stream")
+        geom = [(256, 1, 256, 0), (512, 2, 256, 0), (1024, 1, 1024, 0), (2048, 4, 512, 1), (4096, 8, 512, 1), (5120, 10, 512, 1)]
+        kname = next(("k_eval_cubes<%d,%d,8,%s>" % (b, p, "true" if j else "false") for lim, p, b, j in geom if nd <= lim), "k_eval_cubes_stream")
         label = "configs[2]" if default_shape else ("configs[4] shape" if nd >= 50000 else "non-default shape")
         line = {
             "metric": "translation_bnb_cube_evals_per_sec", "value": value, "unit": "cube-evals/s", "n_gpus": world, "steps": args.steps,

@@ -300,10 +300,13 @@ struct TileShm {
 // registers. Results: sh.ub[], sh.lb[] (geometric part only; the penalty part is added by the caller).
 // Restates reference jly_goicp.cpp:343-415.
 // NT = cubes of the tile (TC everywhere today; 4-cube tiles with two 512-lane workgroups per CU measured no faster)
-template <int BLOCK, int PPT, bool OCT, int NT>
+// JIT = true: the lane's points are not held in registers; point m is fetched from `jit_rot` / `jit_rho` just before its gathers
+// (one point ahead), which frees the registers a second workgroup per CU needs (512 lanes x 10 points, k_eval_cubes only).
+template <int BLOCK, int PPT, bool OCT, int NT, bool JIT = false>
 __device__ __forceinline__ void sweep_tile(const DevTables& T, TileShm<BLOCK>& sh, const float (&px)[PPT], const float (&py)[PPT],
                                            const float (&pz)[PPT], const float (&pw)[PPT], const float (&prho)[PPT], bool use_rho,
-                                           float* rbuf /* LDS, exact mode only */, bool row_mode = false /* !OCT: the cubes share y and z */) {
+                                           float* rbuf /* LDS, exact mode only */, bool row_mode = false /* !OCT: the cubes share y and z */,
+                                           const float4* __restrict__ jit_rot = nullptr, const float* __restrict__ jit_rho = nullptr) {
     const int tid = threadIdx.x;
     const int Nd = T.Nd;
     float r[NT][PPT];
@@ -312,7 +315,7 @@ __device__ __forceinline__ void sweep_tile(const DevTables& T, TileShm<BLOCK>& s
     // formed on the rare lanes that need it, after the fetch.
     // Lanes past Nd carry a zero point with zero weight (their residuals are never counted).
     const int S = T.S;
-    auto cells = [&](int m, unsigned (&idx)[NT]) -> unsigned {
+    auto cells = [&](float X, float Y, float Z, unsigned (&idx)[NT]) -> unsigned {
         unsigned oob = 0u;
         if (OCT) {
             // the 8 cubes are the 2x2x2 children of one node: child j sits at (j&1, j>>1&1, j>>2&1), so only two distinct
@@ -320,9 +323,9 @@ __device__ __forceinline__ void sweep_tile(const DevTables& T, TileShm<BLOCK>& s
             int rx[2], ry[2], rz[2];
 #pragma unroll
             for (int q = 0; q < 2; q++) {
-                rx[q] = cell_of(px[m] + sh.cen[q][0], T.xMin, T.scale);
-                ry[q] = cell_of(py[m] + sh.cen[2 * q][1], T.yMin, T.scale);
-                rz[q] = cell_of(pz[m] + sh.cen[4 * q][2], T.zMin, T.scale);
+                rx[q] = cell_of(X + sh.cen[q][0], T.xMin, T.scale);
+                ry[q] = cell_of(Y + sh.cen[2 * q][1], T.yMin, T.scale);
+                rz[q] = cell_of(Z + sh.cen[4 * q][2], T.zMin, T.scale);
             }
 #pragma unroll
             for (int j = 0; j < NT; j++) {
@@ -333,47 +336,55 @@ __device__ __forceinline__ void sweep_tile(const DevTables& T, TileShm<BLOCK>& s
         } else if (row_mode) {
             // the 8 cubes form a row (same y and z centre, e.g. 8 x-neighbours of a level grid): the y and z cell
             // arithmetic is shared, 10 axis computations instead of 24
-            const int y = cell_of(py[m] + sh.cen[0][1], T.yMin, T.scale), z = cell_of(pz[m] + sh.cen[0][2], T.zMin, T.scale);
+            const int y = cell_of(Y + sh.cen[0][1], T.yMin, T.scale), z = cell_of(Z + sh.cen[0][2], T.zMin, T.scale);
             const int rowbase = (clamp_cell(z, S) * S + clamp_cell(y, S)) * S;
             const unsigned yz_out = (((unsigned)y >= (unsigned)S) | ((unsigned)z >= (unsigned)S)) ? 1u : 0u;
 #pragma unroll
             for (int j = 0; j < NT; j++) {
-                const int x = cell_of(px[m] + sh.cen[j][0], T.xMin, T.scale);
+                const int x = cell_of(X + sh.cen[j][0], T.xMin, T.scale);
                 idx[j] = (unsigned)(rowbase + clamp_cell(x, S));
                 oob |= (yz_out | (((unsigned)x >= (unsigned)S) ? 1u : 0u)) << j;
             }
         } else {
 #pragma unroll
             for (int j = 0; j < NT; j++) {
-                const int x = cell_of(px[m] + sh.cen[j][0], T.xMin, T.scale), y = cell_of(py[m] + sh.cen[j][1], T.yMin, T.scale), z = cell_of(pz[m] + sh.cen[j][2], T.zMin, T.scale);
+                const int x = cell_of(X + sh.cen[j][0], T.xMin, T.scale), y = cell_of(Y + sh.cen[j][1], T.yMin, T.scale), z = cell_of(Z + sh.cen[j][2], T.zMin, T.scale);
                 idx[j] = (unsigned)((clamp_cell(z, S) * S + clamp_cell(y, S)) * S + clamp_cell(x, S));
                 oob |= ((((unsigned)x >= (unsigned)S) | ((unsigned)y >= (unsigned)S) | ((unsigned)z >= (unsigned)S)) ? 1u : 0u) << j;
             }
         }
         return oob;
     };
+    float4 pnext = make_float4(0.f, 0.f, 0.f, 0.f); float rnext = 0.f;
+    if (JIT) { const int i0 = min(tid, Nd - 1); pnext = jit_rot[i0]; rnext = jit_rho ? jit_rho[i0] : 0.f; }
 #pragma unroll
     for (int m = 0; m < PPT; m++) {
+        float X, Y, Z, W, RH;
+        if (JIT) {
+            X = pnext.x; Y = pnext.y; Z = pnext.z; W = pnext.w; RH = rnext;
+            if (m + 1 < PPT) { const int in = min(tid + (m + 1) * BLOCK, Nd - 1); pnext = jit_rot[in]; rnext = jit_rho ? jit_rho[in] : 0.f; }
+        } else { X = px[m]; Y = py[m]; Z = pz[m]; W = pw[m]; RH = prho[m]; }
         unsigned idx[NT]; float v[NT];
-        const unsigned oob = cells(m, idx);
+        const unsigned oob = cells(X, Y, Z, idx);
 #pragma unroll
         for (int j = 0; j < NT; j++) v[j] = T.dist[(T.dbg & 2) ? (idx[j] & 1023u) : idx[j]];
         if (__any((int)oob)) {
 #pragma unroll
             for (int j = 0; j < NT; j++) {
                 if ((oob >> j) & 1u) {
-                    float ext; (void)dt_index(T, px[m] + sh.cen[j][0], py[m] + sh.cen[j][1], pz[m] + sh.cen[j][2], ext);
+                    float ext; (void)dt_index(T, X + sh.cen[j][0], Y + sh.cen[j][1], Z + sh.cen[j][2], ext);
                     v[j] = dt_finish(T, v[j], ext);
                 }
             }
         }
 #pragma unroll
         for (int j = 0; j < NT; j++) {
-            float d = pw[m] * v[j];
-            if (use_rho) d -= prho[m];
+            float d = W * v[j];
+            if (use_rho) d -= RH;
             if (d < 0.f) d = 0.f;
             r[j][m] = d;
         }
+        if (JIT) __builtin_amdgcn_sched_barrier(0);        // keep the point fetches one ahead instead of all up front
     }
     if (BLOCK * PPT <= 1024 && T.exact && T.doTrim) {
         // parity mode, trimmed: residual rows to LDS, one lane per cube runs the reference's selection (same swaps, same final
@@ -1377,8 +1388,8 @@ __global__ __launch_bounds__(1024) void k_eval_cubes_stream(DevTables T, const f
 // ---------------------------------------------------------------------------------------------
 // k_eval_cubes: 8 free cubes per workgroup; cloud = rotation slot prepared by k_rotate
 // ---------------------------------------------------------------------------------------------
-template <int BLOCK, int PPT, int NT>
-__global__ __launch_bounds__(BLOCK) void k_eval_cubes(DevTables T, const float4* __restrict__ rot_all /*[slots][Nd] x,y,z,weight*/, int slot0, int level0,
+template <int BLOCK, int PPT, int NT, bool JIT = false>
+__global__ __launch_bounds__(BLOCK, (JIT ? 4 : 1)) void k_eval_cubes(DevTables T, const float4* __restrict__ rot_all /*[slots][Nd] x,y,z,weight*/, int slot0, int level0,
                                                        const int2* __restrict__ groups /* (slot, rot_level) per blockIdx.y, or null */,
                                                        const float* __restrict__ cubes, int n, float* __restrict__ ub_out, float* __restrict__ lb_out,
                                                        float* fpscratch) {
@@ -1395,7 +1406,11 @@ __global__ __launch_bounds__(BLOCK) void k_eval_cubes(DevTables T, const float4*
     float* fpbuf = fpscratch ? fpscratch + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * NLMAX * Nd : nullptr;
     float px[PPT], py[PPT], pz[PPT], pw[PPT], prho[PPT];
     const bool use_rho = rot_level >= 0;
-    {   // all loads first (clamped index instead of a branch), one wait for the lot
+    const float* rho_row_jit = use_rho ? T.maxRotDis + (size_t)rot_level * Nd : nullptr;
+    if (JIT) {
+#pragma unroll
+        for (int m = 0; m < PPT; m++) { px[m] = py[m] = pz[m] = pw[m] = prho[m] = 0.f; }
+    } else {   // all loads first (clamped index instead of a branch), one wait for the lot
         float4 p[PPT]; float rh[PPT];
         const float* rho_row = T.maxRotDis + (size_t)(use_rho ? rot_level : 0) * Nd;
 #pragma unroll
@@ -1422,7 +1437,7 @@ __global__ __launch_bounds__(BLOCK) void k_eval_cubes(DevTables T, const float4*
         sh.lat[tid][1] = sh.cube[j][1] + (c >> 1 & 1) * sh.cube[j][3];
         sh.lat[tid][2] = sh.cube[j][2] + (c >> 2 & 1) * sh.cube[j][3];
     }
-    sweep_tile<BLOCK, PPT, false, NT>(T, sh, px, py, pz, pw, prho, use_rho, rbuf, row);
+    sweep_tile<BLOCK, PPT, false, NT, JIT>(T, sh, px, py, pz, pw, prho, use_rho, rbuf, row, rot, rho_row_jit);
     if (penalties) lattice_terms<BLOCK, PPT>(T, sh, 8 * NT, px, py, pz, fpbuf);
     if (tid < NT && base + tid < n) {
         const int j = tid;
@@ -1955,7 +1970,15 @@ static int launch_eval(goicp_engine* h, int slot, int rot_level, const int2* gro
     int rc = ensure_fpscratch(h, (size_t)tiles * ngroups);
     if (rc != GOICP_OK) return rc;
 #define CALL(B, P) hipLaunchKernelGGL((k_eval_cubes<B, P, TC>), dim3(tiles, ngroups), dim3(B), h->dyn_lds, h->stream, h->T, h->d_rot, slot, rot_level, groups_dev, (const float*)cubes_dev, n, (float*)ub_dev, (float*)lb_dev, h->d_fpscratch)
-    DISPATCH_GEOM(h, CALL);
+    // clouds of 1025..5120 points without penalty terms: 512 lanes x twice the points, the points fetched just in time instead of
+    // held in registers -> 128 VGPRs, two workgroups per CU, one gathering while the other selects (3.89 -> 3.52 ms at C3)
+    const bool jit = h->block == 1024 && h->ppt >= 2 && !h->T.exact && !h->T.use_compat && !h->T.use_fpfh && !(getenv("GOICP_JIT") && atoi(getenv("GOICP_JIT")) == 0);
+#define CALLJ(P2) hipLaunchKernelGGL((k_eval_cubes<512, P2, TC, true>), dim3(tiles, ngroups), dim3(512), h->dyn_lds, h->stream, h->T, h->d_rot, slot, rot_level, groups_dev, (const float*)cubes_dev, n, (float*)ub_dev, (float*)lb_dev, h->d_fpscratch)
+    if (jit && h->ppt == 2) CALLJ(4);
+    else if (jit && h->ppt == 4) CALLJ(8);
+    else if (jit && h->ppt == 5) CALLJ(10);
+    else DISPATCH_GEOM(h, CALL);
+#undef CALLJ
 #undef CALL
     HIPCHK(h, hipGetLastError());
     h->n_cubes += (uint64_t)n * ngroups; h->n_lookups += (uint64_t)n * ngroups * h->T.Nd;
