@@ -1191,8 +1191,10 @@ __device__ __forceinline__ void sweep_stream(const DevTables& T, TileShm<BLOCK>&
 // STREAM = true (BLOCK 1024, PPT 1, PEN false): clouds above 8192 points; the rotated cloud lives in the workgroup's slice of
 // T.srot and every pop streams it through sweep_stream instead of holding it in registers.
 // (256-lane geometries: at most 256 registers per lane, so that two searches share a CU)
-template <int BLOCK, int PPT, bool PEN, bool STREAM = false>
-__global__ __launch_bounds__(BLOCK, (BLOCK == 256 ? 2 : 1)) void k_inner_bnb(DevTables T, const goicp_bnb_job* __restrict__ jobs, goicp_bnb_result* __restrict__ results,
+// JIT = true (BLOCK 512, PPT 4, PEN false): geometric searches of 1025..2048 points; the rotated cloud also lives in T.srot, but the
+// residuals stay in registers (sweep_tile fetches point m just before its gathers) -> 128 VGPRs, two searches per CU.
+template <int BLOCK, int PPT, bool PEN, bool STREAM = false, bool JIT = false>
+__global__ __launch_bounds__(BLOCK, (BLOCK == 256 ? 2 : (JIT ? 4 : 1))) void k_inner_bnb(DevTables T, const goicp_bnb_job* __restrict__ jobs, goicp_bnb_result* __restrict__ results,
                                                       HeapNode* heaps, int heap_cap, float* fpscratch, unsigned max_pops, int heap_lds_nodes, int rbuf_floats, int fp_lds) {
     __shared__ TileShm<BLOCK> sh;
     __shared__ HeapNode parent;
@@ -1209,7 +1211,7 @@ __global__ __launch_bounds__(BLOCK, (BLOCK == 256 ? 2 : 1)) void k_inner_bnb(Dev
     float px[PPT], py[PPT], pz[PPT], pw[PPT], prho[PPT];
     const bool use_rho = job.rot_level >= 0;
     float4* srot = nullptr; float* srows = nullptr; const float* srho = nullptr;
-    if constexpr (STREAM) {
+    if constexpr (STREAM || JIT) {
         srot = T.srot + (size_t)blockIdx.x * T.NdP;
         srows = T.srows ? T.srows + (size_t)blockIdx.x * TC * T.NdP : nullptr;
         srho = use_rho ? T.maxRotDis + (size_t)job.rot_level * Nd : nullptr;
@@ -1296,6 +1298,7 @@ __global__ __launch_bounds__(BLOCK, (BLOCK == 256 ? 2 : 1)) void k_inner_bnb(Dev
         __syncthreads();
         STAMP(1);
         if constexpr (STREAM) sweep_stream<true>(T, sh, srot, srho, srows, T.NdP);
+        else if constexpr (JIT) sweep_tile<BLOCK, PPT, true, TC, true>(T, sh, px, py, pz, pw, prho, use_rho, rbuf, false, srot, srho);
         else sweep_tile<BLOCK, PPT, true, TC>(T, sh, px, py, pz, pw, prho, use_rho, rbuf);
         STAMP(2);
         if (PEN && T.use_compat) lattice_compat_oct<BLOCK, PPT>(T, sh, px, py, pz);
@@ -1571,7 +1574,8 @@ struct goicp_engine {
     float* d_dist; int* d_int; float* d_lat; int lat_cap; int* d_cnt; float* d_fp;
     int block, ppt; size_t dyn_lds; size_t dyn_lds_bnb; int heap_lds_nodes; int rbuf_floats; int fp_lds;
     int resident_jobs;                       // search workgroups resident at once (CUs x occupancy of the chosen k_inner_bnb)
-    int streamed; size_t stream_wgs, stream_rot_wgs;        // streaming path (Nd > 8192): scratch sized for this many resident workgroups
+    int streamed; size_t stream_wgs, stream_rot_wgs;   // streaming path: scratch sized for this many resident workgroups (rows / rotated clouds)
+    int jit_bnb;                             // geometric searches of 1025..2048 points: k_inner_bnb<512, 4, false, false, true>
     unsigned max_pops;
     uint64_t n_cubes, n_lookups; double kernel_ms;
     std::string err;
@@ -1879,6 +1883,10 @@ extern "C" int goicp_engine_create(const goicp_engine_desc* d, goicp_engine** ou
         DISPATCH_GEOM(h, SETATTR);
 #undef SETATTR
         if (h->streamed) CRH(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_inner_bnb<1024, 1, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->dyn_lds_bnb));
+        // measured (tools/mid_perf.py): 2 000 points 15.2 -> 12.9 ms of kernel time, 4 000 points no change, 5 000 points 7 % slower
+        // (122 spilled registers), so only the 1025..2048-point geometry switches. GOICP_JIT_BNB=0 disables.
+        h->jit_bnb = (!h->streamed && h->block == 1024 && h->ppt == 2 && !T.exact && !T.use_compat && !T.use_fpfh && !(getenv("GOICP_JIT_BNB") && atoi(getenv("GOICP_JIT_BNB")) == 0)) ? 1 : 0;
+        if (h->jit_bnb) CRH(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_inner_bnb<512, 4, false, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->dyn_lds_bnb));
         {
             int ncu = 0; CRH(hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, h->device));   // (a full hipGetDeviceProperties costs ~1 ms per engine)
             int nb = 0;
@@ -1886,6 +1894,7 @@ extern "C" int goicp_engine_create(const goicp_engine_desc* d, goicp_engine** ou
 #define OCC(B, P) do { if (pen) CRH(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_inner_bnb<B, P, true>, B, h->dyn_lds_bnb)); \
                        else CRH(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_inner_bnb<B, P, false>, B, h->dyn_lds_bnb)); } while (0)
             if (h->streamed) CRH(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_inner_bnb<1024, 1, false, true>, 1024, h->dyn_lds_bnb));
+            else if (h->jit_bnb) CRH(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_inner_bnb<512, 4, false, false, true>, 512, h->dyn_lds_bnb));
             else DISPATCH_GEOM(h, OCC);
 #undef OCC
             h->resident_jobs = std::max(1, nb) * std::max(1, ncu);
@@ -1941,7 +1950,7 @@ static int ensure_fpscratch(goicp_engine* h, size_t blocks) {
     return GOICP_OK;
 }
 
-static int ensure_stream_scratch(goicp_engine* h, size_t wgs, bool need_rot) {
+static int ensure_stream_scratch(goicp_engine* h, size_t wgs, bool need_rot, bool need_rows = true) {
     // per resident workgroup: rotated cloud (search kernel only) + TC residual rows (trimmed runs only)
     if (need_rot && wgs > h->stream_rot_wgs) {
         HIPCHK(h, hipStreamSynchronize(h->stream));
@@ -1950,7 +1959,7 @@ static int ensure_stream_scratch(goicp_engine* h, size_t wgs, bool need_rot) {
         HIPCHK(h, cache_malloc((void**)&h->T.srot, wgs * (size_t)h->T.NdP * sizeof(float4), h->device));
         h->stream_rot_wgs = wgs;
     }
-    if (h->T.doTrim && wgs > h->stream_wgs) {
+    if (need_rows && h->T.doTrim && wgs > h->stream_wgs) {
         HIPCHK(h, hipStreamSynchronize(h->stream));
         if (h->T.srows) { cache_free(h->T.srows); h->T.srows = nullptr; }
         h->stream_wgs = 0;
@@ -2078,6 +2087,7 @@ static int run_bnb(goicp_engine* h, const goicp_bnb_job* jobs, int njobs, goicp_
     int rc = ensure_fpscratch(h, (size_t)njobs);
     if (rc != GOICP_OK) return rc;
     if (h->streamed) { rc = ensure_stream_scratch(h, (size_t)njobs, true); if (rc != GOICP_OK) return rc; }
+    if (h->jit_bnb) { rc = ensure_stream_scratch(h, (size_t)njobs, true, false); if (rc != GOICP_OK) return rc; }
     // job descriptors and results go through the pooled pinned buffer when they fit: the kernel reads its job and writes its
     // result over the bus, so a launch costs no staging copies
     const bool zero_copy = h->pinned && (size_t)njobs * (sizeof(goicp_bnb_job) + sizeof(goicp_bnb_result)) <= PINNED_BYTES;
@@ -2089,8 +2099,11 @@ static int run_bnb(goicp_engine* h, const goicp_bnb_job* jobs, int njobs, goicp_
     HIPCHK(h, hipEventRecord(h->ev0, h->stream));
 #define CALL(B, P) do { if (h->T.use_compat || h->T.use_fpfh) hipLaunchKernelGGL((k_inner_bnb<B, P, true>), dim3(njobs), dim3(B), h->dyn_lds_bnb, h->stream, h->T, k_jobs, k_results, heaps, cap, h->d_fpscratch, h->max_pops, h->heap_lds_nodes, h->rbuf_floats, h->fp_lds); \
                         else hipLaunchKernelGGL((k_inner_bnb<B, P, false>), dim3(njobs), dim3(B), h->dyn_lds_bnb, h->stream, h->T, k_jobs, k_results, heaps, cap, h->d_fpscratch, h->max_pops, h->heap_lds_nodes, h->rbuf_floats, h->fp_lds); } while (0)
+#define CALLJ(P2) hipLaunchKernelGGL((k_inner_bnb<512, P2, false, false, true>), dim3(njobs), dim3(512), h->dyn_lds_bnb, h->stream, h->T, k_jobs, k_results, heaps, cap, h->d_fpscratch, h->max_pops, h->heap_lds_nodes, h->rbuf_floats, h->fp_lds)
     if (h->streamed) hipLaunchKernelGGL((k_inner_bnb<1024, 1, false, true>), dim3(njobs), dim3(1024), h->dyn_lds_bnb, h->stream, h->T, k_jobs, k_results, heaps, cap, h->d_fpscratch, h->max_pops, h->heap_lds_nodes, h->rbuf_floats, h->fp_lds);
+    else if (h->jit_bnb) CALLJ(4);
     else DISPATCH_GEOM(h, CALL);
+#undef CALLJ
 #undef CALL
     HIPCHK(h, hipGetLastError());
     HIPCHK(h, hipEventRecord(h->ev1, h->stream));

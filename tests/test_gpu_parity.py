@@ -187,7 +187,7 @@ def test_speculative_batching_does_not_change_the_result():
     assert outs[2]["stats"]["inner_launches"] < outs[1]["stats"]["inner_launches"] < outs[0]["stats"]["inner_launches"]
 
 
-@pytest.mark.parametrize("n,S,trim", [(1000, 100, 0.0), (1000, 100, 0.1), (5000, 100, 0.1), (3000, 60, 0.0)])
+@pytest.mark.parametrize("n,S,trim", [(1000, 100, 0.0), (1000, 100, 0.1), (5000, 100, 0.1), (3000, 60, 0.0), (2000, 60, 0.1), (1500, 60, 0.0)])
 def test_synthetic_cloud_against_oracle(n, S, trim):
     """Seeded synthetic pair (SURVEY.md 8(d) generator), geometric path: cube tables + InnerBnB vs the oracle."""
     P = synth_pair(n, seed=20260101 + n)
