@@ -1305,8 +1305,9 @@ __global__ __launch_bounds__(BLOCK, (BLOCK == 256 ? 2 : (JIT ? 4 : 1))) void k_i
         STAMP(3);
         if (PEN && T.use_fpfh) lattice_fpfh_oct<BLOCK, PPT>(T, sh, px, py, pz, fpbuf);
         STAMP(4);
-        if (penalties) {
-            // lanes 0-7 fold the corner terms of their child into sh.ub/sh.lb in parallel ...
+        if (penalties && tid < 64) {
+            // lanes 0-7 of wave 0 fold the corner terms of their child into sh.ub/sh.lb in parallel (only wave 0 reads them next,
+            // so a wave-level fence replaces a workgroup barrier) ...
             if (tid < TC) {
                 const int j = tid;
                 float ub = sh.ub[j], lb = sh.lb[j];
@@ -1322,7 +1323,7 @@ __global__ __launch_bounds__(BLOCK, (BLOCK == 256 ? 2 : (JIT ? 4 : 1))) void k_i
                 if (T.use_fpfh) { ub += T.regFPFH * (maxF * maxF); lb += T.regFPFH * (minF * minF); }
                 sh.ub[j] = ub; sh.lb[j] = lb;
             }
-            __syncthreads();
+            wave_sync_lds();
         }
         if (tid < 64) {
             // ... and wave 0 replays the order-dependent part with uniform control flow (every lane carries the same search
