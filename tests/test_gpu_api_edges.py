@@ -154,3 +154,29 @@ def test_non_finite_coordinates_are_refused_and_tiny_clouds_register():
         out = g.register()
         assert np.isfinite(out["error"]) and np.all(np.isfinite(out["R"])) and np.all(np.isfinite(out["t"]))
         g.close()
+
+
+def test_pooled_device_resources_can_be_released_and_switched_off():
+    """Engines park their device blocks, stream/event triples and pinned buffer for the next engine; releasing the pool, and
+    running with GOICP_CACHE_GB=0 (every engine allocates and frees for itself), must not change a result."""
+    import json, subprocess, sys
+    from helpers import load_register
+    G = load_register()["pair1_default"]; P = load_clouds("pair1")
+    from oracle.refbind import cfg_vector
+
+    def reg():
+        g = goicp_amd.GoICP(cfg_vector(**G["cfg"])[0]); g.set_clouds(P["t"], P["s"], P["tc"], P["sc"], P["tf"], P["sf"]); g.build_dt()
+        out = g.register(); g.close()
+        return float(out["error"]), out["comp"]
+    first = reg()
+    goicp_amd.load_library().goicp_engine_release_cached_memory()
+    assert reg() == first == (G["error"], G["comp"])
+    code = ("import sys; sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
+            "import goicp_amd\nfrom helpers import load_register, load_clouds\nfrom oracle.refbind import cfg_vector\n"
+            "G = load_register()['pair1_default']; P = load_clouds('pair1')\n"
+            "for _ in range(3):\n"
+            "    g = goicp_amd.GoICP(cfg_vector(**G['cfg'])[0]); g.set_clouds(P['t'], P['s'], P['tc'], P['sc'], P['tf'], P['sf']); g.build_dt(); o = g.register(); g.close()\n"
+            "    assert float(o['error']) == G['error'] and o['comp'] == G['comp']\n"
+            "print('ok')\n") % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))), os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=120, env=dict(os.environ, GOICP_CACHE_GB="0"))
+    assert out.returncode == 0 and out.stdout.strip().endswith("ok"), out.stderr[-1500:]
