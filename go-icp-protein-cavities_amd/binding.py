@@ -216,7 +216,7 @@ class Engine:
 class GoICP:
     """Registration-level surface (GoICP::BuildDT / Register) through include/goicp_c.h."""
 
-    def __init__(self, cfgvec=None, device_id=0, parity_mode=1, speculate=32, verbose=0):
+    def __init__(self, cfgvec=None, device_id=0, parity_mode=1, speculate=128, verbose=0):
         self.L = load_library()
         self.h = C.c_void_p(self.L.goicp_new())
         self.Nd = self.Nm = 0

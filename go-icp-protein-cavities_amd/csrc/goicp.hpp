@@ -106,7 +106,7 @@ public:
     // --- additions of this build (not in the reference) ---
     int device_id = 0;
     int parity_mode = 1;          // see goicp_engine_desc::parity_mode
-    int speculate = 32;           // 0: one InnerBnB per launch; 1: the <=16 calls of a rotation pop per launch; M>1: also those of the next M-1 queue nodes
+    int speculate = 128;           // 0: one InnerBnB per launch; 1: the <=16 calls of a rotation pop per launch; M>1: also those of the next M-1 queue nodes
     uint32_t spec_pop_budget = 20000;   // queue-pop budget of a speculative job (re-run unbounded if it turns out to be needed)
     int verbose = 0;              // echo the reference's "Error*: ..." progress lines to stdout
     int status = GOICP_OK;        // last engine status

@@ -8,7 +8,7 @@ import goicp_amd
 from oracle.refbind import cfg_vector, read_txt_cloud
 from helpers import load_clouds, load_register, GOLDEN, synth_pair
 
-def run(name, P, cfgd, spec=32):
+def run(name, P, cfgd, spec=128):
     v = cfg_vector(**cfgd)[0]
     g = goicp_amd.GoICP(v, speculate=spec)
     g.set_clouds(P["t"], P["s"], P.get("tc"), P.get("sc"), P.get("tf"), P.get("sf"))
