@@ -11,7 +11,7 @@ rng = np.random.default_rng(9000 + 7); n = int(rng.integers(120, 420))
 cases.append(("color8_hard", synth_pair(n, seed=31007, noise=0.01, outlier_frac=float(rng.choice([0.0, 0.05, 0.15])), theta_range=(0.3, np.pi), corr_features=True),
               goicp_amd.cfg_vector(cfpfh=3, regularizationFPFH=0.00005, regularization=0.0)))
 for name, P, v in cases:
-    for spec in (32, 128):
+    for spec in (128,):
         g = goicp_amd.GoICP(v, speculate=spec)
         g.set_clouds(P["t"], P["s"], P["tc"], P["sc"], P["tf"], P["sf"]); g.build_dt()
         t0 = time.perf_counter(); o = g.register(); dt = time.perf_counter() - t0
