@@ -620,12 +620,12 @@ float GoICP::OuterBnB() {
             add_jobs(plan, first, false, jobs, where);
             if (speculate > 1 && !queueRot.empty()) {
                 RotHeap peek = queueRot;
-                // Launch size: up to four times the jobs the device holds at once -- most jobs are short, so the later workgroups start
+                // Launch size: up to eight times the jobs the device holds at once (2048 at most) -- most jobs are short, so the later workgroups start
                 // while the few long searches of the launch are still running (a hard cavity pair with 37 M cube evaluations: 1.56 s
-                // at one wave of workgroups, 0.89 s here). The depth grows with the length of the search: easy pairs end within a few
+                // at one wave of workgroups, 0.98 s at four, 0.89 s here). The depth grows with the length of the search: easy pairs end within a few
                 // launches and should not pay for jobs that are never consumed (8 nodes for launches 0-2, then 16, 32, 64, and
                 // `speculate` = 128 from the 24th launch on).
-                const int max_jobs = std::min(2048, std::max(32, 4 * goicp_engine_resident_jobs(eng_)));
+                const int max_jobs = std::min(2048, std::max(32, 8 * goicp_engine_resident_jobs(eng_)));
                 const int depth = std::min(speculate, stats.inner_launches >= 24 ? 128 : 8 << std::min(3, (int)(stats.inner_launches / 3)));
                 for (int m = 1; m < depth && !peek.empty() && (int)jobs.size() + 16 <= max_jobs; m++) {
                     const ROTNODE nd = peek.top(); peek.pop();
