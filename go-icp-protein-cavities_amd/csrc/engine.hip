@@ -1205,7 +1205,8 @@ __global__ __launch_bounds__(BLOCK, (BLOCK == 256 ? 2 : (JIT ? 4 : 1))) void k_i
     HeapStore heap;
     heap.glb = heaps + (size_t)blockIdx.x * heap_cap; heap.lds = reinterpret_cast<HeapNode*>(rbuf + rbuf_floats); heap.hl = heap_lds_nodes;
     float* fpbuf = fpscratch ? fpscratch + (size_t)blockIdx.x * NLMAX * Nd : nullptr;
-    if (fp_lds) fpbuf = rbuf + rbuf_floats + (size_t)heap_lds_nodes * (sizeof(HeapNode) / sizeof(float));     // c-FPFH rows behind the LDS heap
+    if (fp_lds == 1) fpbuf = rbuf + rbuf_floats + (size_t)heap_lds_nodes * (sizeof(HeapNode) / sizeof(float));     // c-FPFH rows behind the LDS heap
+    if (fp_lds == 2) fpbuf = reinterpret_cast<float*>(&sh.hist[0][0]);      // parity mode never touches the select histograms: the rows live there
 
     // K5 fused: pDataTemp = R*p, float, left to right (reference jly_goicp.cpp:750-756)
     float px[PPT], py[PPT], pz[PPT], pw[PPT], prho[PPT];
@@ -1743,7 +1744,10 @@ static void pick_geometry(goicp_engine* h) {
     { const char* e = getenv("GOICP_HEAP_LDS"); if (e && atoi(e) >= 0 && atoi(e) <= 2048) h->heap_lds_nodes = atoi(e); }   // test knob
     h->dyn_lds_bnb = h->dyn_lds + (size_t)h->heap_lds_nodes * sizeof(HeapNode);
     h->fp_lds = 0;
-    if (h->T.use_fpfh && h->dyn_lds_bnb + (size_t)27 * Nd * sizeof(float) + sizeof(TileShm<1024>) + 1024 <= 160 * 1024) { h->fp_lds = 1; h->dyn_lds_bnb += (size_t)27 * Nd * sizeof(float); }
+    // parity mode (Nd <= 1024) leaves the 32 KB of select histograms unused: the 27 c-FPFH rows of a cavity cloud (Nd <= 303) fit
+    // there, which keeps a search at <= 80 KB of LDS, i.e. two searches per CU
+    if (h->T.use_fpfh && h->T.exact && (size_t)27 * Nd * sizeof(float) <= sizeof(unsigned) * TC * 1024) h->fp_lds = 2;
+    else if (h->T.use_fpfh && h->dyn_lds_bnb + (size_t)27 * Nd * sizeof(float) + sizeof(TileShm<1024>) + 1024 <= 160 * 1024) { h->fp_lds = 1; h->dyn_lds_bnb += (size_t)27 * Nd * sizeof(float); }
 }
 
 extern "C" int goicp_engine_create(const goicp_engine_desc* d, goicp_engine** out) {
