@@ -1740,7 +1740,8 @@ static void pick_geometry(goicp_engine* h) {
     h->dyn_lds = h->T.exact ? (size_t)2 * TC * Nd * sizeof(float) : 0;      // ub and lb addend rows (untrimmed) / residual rows (trimmed)
     // k_inner_bnb keeps the top of its queue in LDS behind the residual rows (24 B per node)
     h->rbuf_floats = (int)(h->dyn_lds / sizeof(float));
-    h->heap_lds_nodes = 1024;             // 24 KB: two 256-lane search workgroups fit one CU's LDS next to their tile state
+    h->heap_lds_nodes = 512;              // 12 KB (1024 and 2048 measured no faster): with the residual rows of a cloud of up to ~450
+                                          // points and the tile state a search stays below 80 KB of LDS, so two share a CU
     { const char* e = getenv("GOICP_HEAP_LDS"); if (e && atoi(e) >= 0 && atoi(e) <= 2048) h->heap_lds_nodes = atoi(e); }   // test knob
     h->dyn_lds_bnb = h->dyn_lds + (size_t)h->heap_lds_nodes * sizeof(HeapNode);
     h->fp_lds = 0;
