@@ -1748,7 +1748,13 @@ static void pick_geometry(goicp_engine* h) {
     // parity mode (Nd <= 1024) leaves the 32 KB of select histograms unused: the 27 c-FPFH rows of a cavity cloud (Nd <= 303) fit
     // there, which keeps a search at <= 80 KB of LDS, i.e. two searches per CU
     if (h->T.use_fpfh && h->T.exact && (size_t)27 * Nd * sizeof(float) <= sizeof(unsigned) * TC * 1024) h->fp_lds = 2;
-    else if (h->T.use_fpfh && h->dyn_lds_bnb + (size_t)27 * Nd * sizeof(float) + sizeof(TileShm<1024>) + 1024 <= 160 * 1024) { h->fp_lds = 1; h->dyn_lds_bnb += (size_t)27 * Nd * sizeof(float); }
+    else if (h->T.use_fpfh) {
+        // larger clouds: rows in LDS only if that does not cost the second search per CU (measured on a 379-point cloud with
+        // 37 M cube evaluations: rows in global scratch + two searches per CU 0.77 s, rows in LDS + one search per CU 0.89 s)
+        const size_t tile_state = h->block == 256 ? sizeof(TileShm<256>) : (h->block == 512 ? sizeof(TileShm<512>) : sizeof(TileShm<1024>));
+        const bool two_without_rows = h->block == 256 && h->dyn_lds_bnb + tile_state + 256 <= 80 * 1024;
+        if (!two_without_rows && h->dyn_lds_bnb + (size_t)27 * Nd * sizeof(float) + sizeof(TileShm<1024>) + 1024 <= 160 * 1024) { h->fp_lds = 1; h->dyn_lds_bnb += (size_t)27 * Nd * sizeof(float); }
+    }
 }
 
 extern "C" int goicp_engine_create(const goicp_engine_desc* d, goicp_engine** out) {
