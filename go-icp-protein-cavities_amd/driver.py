@@ -64,20 +64,29 @@ def gather_records(local_records, n_total, dist=None, device=None):
     return allb[order]
 
 
-def run_batch(base_dir, tsv, config, out_dir, register_fn, rank=0, world=1, limit=None):
+def run_batch(base_dir, tsv, config, out_dir, register_fn, rank=0, world=1, limit=None, threads=1):
     """register_fn(target_file, source_file, nd, config, output, k) -> result dict. Pairs whose cavity files are
-    missing are skipped (the reference tree ships 2 of the 383)."""
+    missing are skipped (the reference tree ships 2 of the 383). threads > 1 keeps that many registrations of this rank in
+    flight (one engine + HIP stream each; the C entry points release the GIL); records come back in row order either way."""
     pairs = read_tsv_pairs(tsv)
     if limit:
         pairs = pairs[:limit]
-    recs = []
+    todo = []
     for idx in shard(len(pairs), rank, world):
         src, tgt = pairs[idx]
         k = idx + 1
         sf = os.path.join("cavities", src + "_cavity6.mol2"); tf = os.path.join("cavities", tgt + "_cavity6.mol2")
         if not (os.path.exists(os.path.join(base_dir, sf)) and os.path.exists(os.path.join(base_dir, tf))):
             continue
-        nd = mol2_atom_count(os.path.join(base_dir, sf))
-        res = register_fn(tf, sf, nd, config, os.path.join(out_dir, "similar%d.txt" % k), k)
-        recs.append(pack_record(k, res))
+        todo.append((k, tf, sf, mol2_atom_count(os.path.join(base_dir, sf))))
+
+    def one(job):
+        k, tf, sf, nd = job
+        return pack_record(k, register_fn(tf, sf, nd, config, os.path.join(out_dir, "similar%d.txt" % k), k))
+    if threads > 1 and len(todo) > 1:
+        from concurrent.futures import ThreadPoolExecutor
+        with ThreadPoolExecutor(max_workers=threads) as ex:
+            recs = list(ex.map(one, todo))
+    else:
+        recs = [one(j) for j in todo]
     return recs, len(pairs)

@@ -88,3 +88,12 @@ def test_engine_fails_loudly_without_gpu():
     g.build_dt()
     with pytest.raises(goicp_amd.EngineError):
         g.register()
+
+
+def test_threaded_batch_returns_the_same_records_in_row_order(tmp_path):
+    """run_batch(threads=N) keeps N registrations of a rank in flight; the records must equal the sequential run's, in row order."""
+    tsv = os.path.join(DATA, "cavities_similar_BO1_clean.tsv")
+    seq, n1 = driver.run_batch(DATA, tsv, "unused", str(tmp_path), _fake_register)
+    par, n2 = driver.run_batch(DATA, tsv, "unused", str(tmp_path), _fake_register, threads=4)
+    assert n1 == n2 == 383 and len(seq) == len(par) == 2
+    assert all(np.array_equal(a, b, equal_nan=True) for a, b in zip(seq, par))
