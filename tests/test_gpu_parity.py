@@ -397,6 +397,10 @@ def test_batch_driver_on_one_gpu(tmp_path):
     def reg(tf, sf, nd, config, output, k):
         return goicp_amd.run_pair_files(base, tf, sf, nd, config, output, k)
     recs, n = driver.run_batch(base, os.path.join(base, "cavities_similar_BO1_clean.tsv"), cfgp, outd, reg)
+    # the same batch with both registrations in flight at once (one engine + stream each): same records up to the timing fields
+    recs2, _ = driver.run_batch(base, os.path.join(base, "cavities_similar_BO1_clean.tsv"), cfgp, outd, reg, threads=2)
+    keep = [i for i in range(driver.REC) if i not in (16, 17)]
+    assert all(np.array_equal(a[keep], b[keep], equal_nan=True) for a, b in zip(recs, recs2))
     allr = driver.gather_records(recs, n)
     assert n == 383 and allr.shape[0] == 2
     G = load_register()
