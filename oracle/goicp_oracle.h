@@ -5,7 +5,7 @@
  * (file:line citations into /root/reference are given per function in goicp_oracle.c).
  * Parity status: PINNED -- bit-compared against the compiled reference (oracle/_ref, built by oracle/Makefile
  * from the sources where they lie) and against the reference's shipped goldens (output/similar1.txt,
- * demo/output.txt, cavitiesN/ *.xyz); see tests/test_oracle_vs_ref.py and tests/golden/.
+ * demo/output.txt, cavitiesN/ *.xyz); see tests/test_oracle_golden.py and tests/golden/.
  *
  * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may load this library.
  * The product path (go-icp-protein-cavities_amd/) never links or calls it.
