@@ -12,3 +12,4 @@ from .binding import (LIB_PATH, lib, load_library, Engine, GoICP, EngineError, C
                       GOICP_OK, run_pair_files, run_txt_files, compute_rmsd, apply_transformation_protein)
 from . import driver  # noqa: F401
 from . import synth  # noqa: F401
+from . import c4_batch  # noqa: F401

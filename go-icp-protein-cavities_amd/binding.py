@@ -195,9 +195,13 @@ class Engine:
         self._chk(self.L.goicp_engine_point_eval(self.h, _ptr(R), _ptr(t), _ptr(dist), _ptr(ok)), "point_eval")
         return dist, ok
 
-    def icp_nn(self, R, t):
+    def icp_nn(self, R, t, ties=False):
         R = np.ascontiguousarray(R, dtype=np.float64).reshape(9); t = np.ascontiguousarray(t, dtype=np.float64).reshape(3)
         ids = np.zeros(self.Nd, np.int32); d = np.zeros(self.Nd, np.float32)
+        if ties:
+            nt = np.zeros(self.Nd, np.int32)
+            self._chk(self.L.goicp_engine_icp_nn_ties(self.h, _ptr(R), _ptr(t), _ptr(ids), _ptr(d), _ptr(nt)), "icp_nn_ties")
+            return ids, d, nt
         self._chk(self.L.goicp_engine_icp_nn(self.h, _ptr(R), _ptr(t), _ptr(ids), _ptr(d)), "icp_nn")
         return ids, d
 
@@ -297,8 +301,10 @@ class GoICP:
 
     def icp(self, R, t):
         R = np.ascontiguousarray(R, dtype=np.float64).reshape(9).copy(); t = np.ascontiguousarray(t, dtype=np.float64).reshape(3).copy()
-        e = self.L.goicp_icp(self.h, _ptr(R), _ptr(t), None)
-        return np.float32(e), R.reshape(3, 3), t
+        corr = np.zeros((self.Nd, 2), np.int32); dis = np.zeros(self.Nd, np.float64)
+        e = self.L.goicp_icp(self.h, _ptr(R), _ptr(t), _ptr(corr))
+        self.L.goicp_icp_distances(self.h, _ptr(dis))
+        return np.float32(e), R.reshape(3, 3), t, corr, dis
 
     def record_jobs(self, on=True):
         self.L.goicp_record_jobs(self.h, 1 if on else 0)

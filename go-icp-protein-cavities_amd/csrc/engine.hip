@@ -1529,12 +1529,14 @@ __global__ void k_point_eval(DevTables T, RtArgD rt, float* __restrict__ dist, i
 }
 
 // exhaustive 1-NN in float with the distance expression of the reference's kd-tree metric
-// (jly_icp3d.hpp:54-60). One wave per query point: lane l scans model points l, l+64, ... (strict '<' keeps the
-// first, i.e. lowest, index of its stride), then the wave reduces on (distance, index) so that the lowest model
-// index wins among exact ties.
+// (jly_icp3d.hpp:54-60). One wave per query point: lane l scans model points l, l+64, ... keeping its closest point and how
+// many of its points sit at exactly that distance; the wave then reduces on (distance, index). The reference's kd-tree keeps
+// the FIRST point it meets among exact ties (nanoflann.hpp:1147), which depends on the tree, so the kernel also reports the
+// number of model points at the minimal distance: where it exceeds one, the host names the reference's choice
+// (host_kdorder.hpp); id_out then holds the lowest such index.
 struct RtArg { float v[12]; };                    // float R[9], t[3], passed by value (no staging copy per ICP iteration)
 __global__ __launch_bounds__(256) void k_icp_nn(DevTables T, const float* __restrict__ mxyz, RtArg rt,
-                                                 int* __restrict__ id_out, float* __restrict__ d_out) {
+                                                 int* __restrict__ id_out, float* __restrict__ d_out, int* __restrict__ tie_out) {
     const float* Rt = rt.v;
     const int lane = threadIdx.x & 63;
     const int i = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
@@ -1543,18 +1545,20 @@ __global__ __launch_bounds__(256) void k_icp_nn(DevTables T, const float* __rest
     const float q0 = Rt[0] * d0 + Rt[1] * d1 + Rt[2] * d2 + Rt[9];
     const float q1 = Rt[3] * d0 + Rt[4] * d1 + Rt[5] * d2 + Rt[10];
     const float q2 = Rt[6] * d0 + Rt[7] * d1 + Rt[8] * d2 + Rt[11];
-    float best = INFINITY; int bi = 0x7fffffff;
+    float best = INFINITY; int bi = 0x7fffffff, cnt = 0;
     for (int m = lane; m < T.Nm; m += 64) {
         const float e0 = q0 - mxyz[3 * m], e1 = q1 - mxyz[3 * m + 1], e2 = q2 - mxyz[3 * m + 2];
         const float d = e0 * e0 + e1 * e1 + e2 * e2;
-        if (d < best) { best = d; bi = m; }
+        if (d < best) { best = d; bi = m; cnt = 1; }
+        else if (d == best) cnt++;
     }
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) {
-        const float ob = __shfl_down(best, off, 64); const int oi = __shfl_down(bi, off, 64);
-        if (ob < best || (ob == best && oi < bi)) { best = ob; bi = oi; }
+        const float ob = __shfl_down(best, off, 64); const int oi = __shfl_down(bi, off, 64); const int oc = __shfl_down(cnt, off, 64);
+        if (ob < best) { best = ob; bi = oi; cnt = oc; }
+        else if (ob == best) { cnt += oc; if (oi < bi) bi = oi; }
     }
-    if (lane == 0) { id_out[i] = bi; d_out[i] = best; }
+    if (lane == 0) { id_out[i] = bi; d_out[i] = best; if (tie_out) tie_out[i] = cnt; }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1573,7 +1577,7 @@ struct goicp_engine {
     HeapNode* d_heaps; int heap_cap; size_t heap_jobs; HeapNode* d_heap_big; int heap_big_cap;
     float* d_fpscratch; size_t fp_blocks;
     float* d_cubes; float* d_ub; float* d_lb; int cube_cap; int2* d_groups; std::vector<int2> groups_host;
-    float* d_dist; int* d_int; float* d_lat; int lat_cap; int* d_cnt; float* d_fp;
+    float* d_dist; int* d_int; int* d_tie; float* d_lat; int lat_cap; int* d_cnt; float* d_fp;
     int block, ppt; size_t dyn_lds; size_t dyn_lds_bnb; int heap_lds_nodes; int rbuf_floats; int fp_lds;
     int resident_jobs;                       // search workgroups resident at once (CUs x occupancy of the chosen k_inner_bnb)
     int streamed; size_t stream_wgs, stream_rot_wgs;   // streaming path: scratch sized for this many resident workgroups (rows / rotated clouds)
@@ -1880,6 +1884,7 @@ extern "C" int goicp_engine_create(const goicp_engine_desc* d, goicp_engine** ou
     CR(dev_upload<float>(h, nullptr, h->cube_cap, &h->d_lb));
     CR(dev_upload<float>(h, nullptr, d->Nd, &h->d_dist));
     CR(dev_upload<int>(h, nullptr, d->Nd, &h->d_int));
+    CR(dev_upload<int>(h, nullptr, d->Nd, &h->d_tie));
     h->lat_cap = 1 << 14;
     CR(dev_upload<float>(h, nullptr, (size_t)3 * h->lat_cap, &h->d_lat));
     CR(dev_upload<int>(h, nullptr, h->lat_cap, &h->d_cnt));
@@ -2184,29 +2189,35 @@ extern "C" int goicp_engine_point_eval(goicp_engine* h, const double* R9, const 
     return GOICP_OK;
 }
 
-extern "C" int goicp_engine_icp_nn(goicp_engine* h, const double* R9, const double* t3, int32_t* id_model, float* dist_sq) {
+extern "C" int goicp_engine_icp_nn_ties(goicp_engine* h, const double* R9, const double* t3, int32_t* id_model, float* dist_sq, int32_t* n_tied) {
     if (!h || !R9 || !t3 || !id_model || !dist_sq || h->T.Nm <= 0) return GOICP_ERR_ARG;
     HIPCHK(h, hipSetDevice(h->device));
     RtArg rt;
     for (int k = 0; k < 9; k++) rt.v[k] = (float)R9[k];
     for (int k = 0; k < 3; k++) rt.v[9 + k] = (float)t3[k];
     const size_t Nd = (size_t)h->T.Nd;
-    if (h->pinned && Nd * 8 <= PINNED_BYTES) {
-        // small clouds (every ICP iteration of a cavity pair comes through here): the kernel writes its two result arrays
+    if (h->pinned && Nd * 12 <= PINNED_BYTES) {
+        // small clouds (every ICP iteration of a cavity pair comes through here): the kernel writes its result arrays
         // straight into pinned host memory, so an iteration is one launch and one stream synchronisation
-        int* pid = (int*)h->pinned; float* pd = (float*)h->pinned + Nd;
-        hipLaunchKernelGGL(k_icp_nn, dim3((h->T.Nd + 3) / 4), dim3(256), 0, h->stream, h->T, h->d_mxyz, rt, pid, pd);
+        int* pid = (int*)h->pinned; float* pd = (float*)h->pinned + Nd; int* pt = (int*)h->pinned + 2 * Nd;
+        hipLaunchKernelGGL(k_icp_nn, dim3((h->T.Nd + 3) / 4), dim3(256), 0, h->stream, h->T, h->d_mxyz, rt, pid, pd, n_tied ? pt : nullptr);
         HIPCHK(h, hipGetLastError());
         HIPCHK(h, hipStreamSynchronize(h->stream));
         memcpy(id_model, pid, Nd * sizeof(int)); memcpy(dist_sq, pd, Nd * sizeof(float));
+        if (n_tied) memcpy(n_tied, pt, Nd * sizeof(int));
         return GOICP_OK;
     }
-    hipLaunchKernelGGL(k_icp_nn, dim3((h->T.Nd + 3) / 4), dim3(256), 0, h->stream, h->T, h->d_mxyz, rt, h->d_int, h->d_dist);
+    hipLaunchKernelGGL(k_icp_nn, dim3((h->T.Nd + 3) / 4), dim3(256), 0, h->stream, h->T, h->d_mxyz, rt, h->d_int, h->d_dist, n_tied ? h->d_tie : nullptr);
     HIPCHK(h, hipGetLastError());
     HIPCHK(h, hipMemcpyAsync(id_model, h->d_int, (size_t)h->T.Nd * sizeof(int), hipMemcpyDeviceToHost, h->stream));
     HIPCHK(h, hipMemcpyAsync(dist_sq, h->d_dist, (size_t)h->T.Nd * sizeof(float), hipMemcpyDeviceToHost, h->stream));
+    if (n_tied) HIPCHK(h, hipMemcpyAsync(n_tied, h->d_tie, (size_t)h->T.Nd * sizeof(int), hipMemcpyDeviceToHost, h->stream));
     HIPCHK(h, hipStreamSynchronize(h->stream));
     return GOICP_OK;
+}
+
+extern "C" int goicp_engine_icp_nn(goicp_engine* h, const double* R9, const double* t3, int32_t* id_model, float* dist_sq) {
+    return goicp_engine_icp_nn_ties(h, R9, t3, id_model, dist_sq, nullptr);
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -15,6 +15,7 @@
 #include <vector>
 
 #include "goicp_engine.h"
+#include "host_kdorder.hpp"
 
 namespace goicp {
 
@@ -123,6 +124,10 @@ public:
     void Initialize();                     // reference jly_goicp.cpp:180-267 (+ engine creation)
     void Clear();
     goicp_engine* engine() { return eng_; }
+    // icp3d.points of the last ICP3D run (reference jly_icp3d.hpp:80-85,247-249): ids and squared distances, in the order Run leaves them
+    const std::vector<int32_t>& icp_data_ids() const { return icp_id_data_; }
+    const std::vector<int32_t>& icp_model_ids() const { return icp_id_model_; }
+    const std::vector<double>& icp_distances() const { return icp_dis_; }
     float ICP(Matrix& R_icp, Matrix& t_icp);                      // reference jly_goicp.cpp:102-178
     float InnerBnB(const float* R9, int rot_level, TRANSNODE* nodeTransOut);   // reference jly_goicp.cpp:286-579 (one job)
 
@@ -131,7 +136,9 @@ private:
     double icp_ms_ = 0;
     std::vector<float> normData_, minDis_;
     std::vector<int32_t> icp_id_data_, icp_id_model_, opt_id_data_, opt_id_model_;
+    std::vector<double> icp_dis_;
     std::vector<uint32_t> sort_key_, sort_a_, sort_b_;
+    KdOrder kd_order_;                     // the reference kd-tree's visiting order, built on the first exact distance tie
     float OuterBnB();                      // reference jly_goicp.cpp:582-876
     float icp_run(Matrix& R, Matrix& t);   // reference jly_icp3d.hpp:197-311 (1-NN on the device)
     void neighborsWeights();               // reference jly_goicp.cpp:1453-1498

@@ -125,8 +125,25 @@ float goicp_icp(goicp_handle* h, double* R9, double* t3, int32_t* corr) {
     for (int i = 0; i < 3; i++) { for (int j = 0; j < 3; j++) R.val[i][j] = R9[3 * i + j]; t.val[i][0] = t3[i]; }
     const float e = h->g.ICP(R, t);
     for (int i = 0; i < 3; i++) { for (int j = 0; j < 3; j++) R9[3 * i + j] = R.val[i][j]; t3[i] = t.val[i][0]; }
-    (void)corr;
+    if (corr) {                      // icp3d.points of the run just made (reference jly_icp3d.hpp:247-249, after the trimmed sort)
+        const std::vector<int32_t>& idd = h->g.icp_data_ids(); const std::vector<int32_t>& idm = h->g.icp_model_ids();
+        for (size_t i = 0; i < idd.size() && i < idm.size(); i++) { corr[2 * i] = idd[i]; corr[2 * i + 1] = idm[i]; }
+    }
     return e;
+}
+
+int goicp_icp_distances(goicp_handle* h, double* dis) {
+    if (!h || !dis) return GOICP_ERR_ARG;
+    const std::vector<double>& d = h->g.icp_distances();
+    for (size_t i = 0; i < d.size(); i++) dis[i] = d[i];
+    return (int)d.size();
+}
+
+int goicp_kdorder_nn(const float* model_xyz, int Nm, const float* queries_xyz, int n, int32_t* id_model, float* dist_sq) {
+    if (!model_xyz || Nm <= 0 || n < 0 || (n && (!queries_xyz || !id_model))) return GOICP_ERR_ARG;
+    KdOrder kd; kd.build(model_xyz, Nm);
+    for (int i = 0; i < n; i++) { float d = 0; id_model[i] = kd.nearest(queries_xyz + 3 * (size_t)i, &d); if (dist_sq) dist_sq[i] = d; }
+    return GOICP_OK;
 }
 
 static void pack16(const GoICP& g, double* out) {

@@ -201,6 +201,7 @@ GoICP::~GoICP() { Clear(); }
 
 void GoICP::Clear() {
     if (eng_) { goicp_engine_destroy(eng_); eng_ = nullptr; }
+    kd_order_.clear();
 }
 
 void GoICP::log_error(const char* tag, float v) {
@@ -389,7 +390,7 @@ float GoICP::icp_run(Matrix& R, Matrix& t) {
     if (doTrim) num = (int)(n * (1 - trimFraction)); else num = n;
     struct Ref { double dis; int id_data, id_model; };
     std::vector<Ref> pts(n), tmp(n);
-    std::vector<int32_t> ids(n); std::vector<float> dsq(n);
+    std::vector<int32_t> ids(n), tied(n); std::vector<float> dsq(n);
     std::vector<double> p_m((size_t)3 * std::max(num, 1)), p_d((size_t)3 * std::max(num, 1));
     double mu_m[3] = {0, 0, 0}, mu_d[3] = {0, 0, 0};
     double Rd[9], td[3];
@@ -400,8 +401,20 @@ float GoICP::icp_run(Matrix& R, Matrix& t) {
         stats.icp_iters++;
         const float r00 = (float)Rd[0], r01 = (float)Rd[1], r02 = (float)Rd[2], r10 = (float)Rd[3], r11 = (float)Rd[4], r12 = (float)Rd[5];
         const float r20 = (float)Rd[6], r21 = (float)Rd[7], r22 = (float)Rd[8], t0 = (float)td[0], t1 = (float)td[1], t2 = (float)td[2];
-        status = goicp_engine_icp_nn(eng_, Rd, td, ids.data(), dsq.data());
+        status = goicp_engine_icp_nn_ties(eng_, Rd, td, ids.data(), dsq.data(), tied.data());
         if (status != GOICP_OK) return std::numeric_limits<float>::quiet_NaN();
+        for (int i = 0; i < n; i++) if (tied[i] > 1) {
+            // several model points at exactly this distance: the reference's kd-tree keeps the first one it visits
+            // (nanoflann.hpp:1147), so ask the restated tree which one that is
+            if (!kd_order_.built()) {
+                std::vector<float> mx((size_t)3 * Nm);
+                for (int m = 0; m < Nm; m++) { mx[3 * m] = pModel[m].x; mx[3 * m + 1] = pModel[m].y; mx[3 * m + 2] = pModel[m].z; }
+                kd_order_.build(mx.data(), Nm);
+            }
+            const float dx = pData[i].x, dy = pData[i].y, dz = pData[i].z;
+            const float q[3] = {r00 * dx + r01 * dy + r02 * dz + t0, r10 * dx + r11 * dy + r12 * dz + t1, r20 * dx + r21 * dy + r22 * dz + t2};   // jly_icp3d.hpp:239-241
+            ids[i] = kd_order_.nearest(q);
+        }
         err_new = 0;
         for (int i = 0; i < n; i++) { pts[i].dis = dsq[i]; pts[i].id_data = i; pts[i].id_model = ids[i]; }
         if (doTrim) {
@@ -453,8 +466,8 @@ float GoICP::icp_run(Matrix& R, Matrix& t) {
         for (int a = 0; a < 3; a++) { double s = 0; for (int k = 0; k < 3; k++) s += Rn[3 * a + k] * td[k]; tc[a] = s + t_[a]; }
         std::memcpy(Rd, Rc, sizeof Rc); std::memcpy(td, tc, sizeof tc);
     }
-    icp_id_data_.resize(n); icp_id_model_.resize(n);
-    for (int i = 0; i < n; i++) { icp_id_data_[i] = pts[i].id_data; icp_id_model_[i] = pts[i].id_model; }
+    icp_id_data_.resize(n); icp_id_model_.resize(n); icp_dis_.resize(n);
+    for (int i = 0; i < n; i++) { icp_id_data_[i] = pts[i].id_data; icp_id_model_[i] = pts[i].id_model; icp_dis_[i] = pts[i].dis; }
     for (int i = 0; i < 3; i++) { for (int j = 0; j < 3; j++) R.val[i][j] = Rd[3 * i + j]; t.val[i][0] = td[i]; }
     return err_new;
 }

@@ -1,12 +1,21 @@
-"""Batch driver: the role of the reference's bo1_GoICP.py (one registration per .tsv row) with the pairs
-sharded over the GPUs of one node -- one process per GPU, no data-path collective; a single all_gather of
-fixed-size result records at the end."""
+"""Batch driver: the role of the reference's bo1_GoICP.py (one registration per .tsv row, reference bo1_GoICP.py:6-51) with the
+pairs sharded over the GPUs of one node -- one process per GPU, no data-path collective; a single all_gather of fixed-size
+result records (the RMSD of every pair among them) at the end.
+
+Scheduling. Pair cost varies by orders of magnitude (0.06 s vs 35 s on the reference), so the rows are taken
+longest-first by a cheap cost proxy (source atoms x target atoms):
+  * schedule="dynamic" (default when a process group is up): every rank's worker threads draw the next row of the sorted
+    list from ONE shared counter (an atomic add on the process group's key-value store -- control path only, a few bytes per
+    pair), so a rank that finishes early keeps pulling work;
+  * schedule="lpt": static greedy longest-processing-time assignment (each row to the least-loaded rank), no communication;
+  * schedule="rr": row k -> rank k mod world (kept for reference).
+"""
 import os
-import time
+import threading
 
 import numpy as np
 
-REC = 24   # floats per result record: pair id, R[9], t[3], error, compat, Nd, seconds, dt_seconds, cube_evals, rmsd, status, pad
+REC = 24   # floats per result record: pair id, R[9], t[3], error, compat, Nd, seconds, dt_seconds, cube_evals, rmsd, status, rank, pad
 
 
 def read_tsv_pairs(path):
@@ -34,19 +43,61 @@ def shard(n_items, rank, world):
     return list(range(rank, n_items, world))
 
 
-def pack_record(pair_id, res, rmsd=float("nan")):
+def lpt_order(costs):
+    """indices by decreasing cost (stable: equal costs keep row order)."""
+    return sorted(range(len(costs)), key=lambda i: (-costs[i], i))
+
+
+def lpt_assign(costs, world):
+    """greedy longest-processing-time partition: rows in decreasing cost, each to the least-loaded rank (lowest rank on ties).
+    Returns one index list per rank, each in decreasing cost."""
+    load = [0.0] * world
+    out = [[] for _ in range(world)]
+    for i in lpt_order(costs):
+        r = min(range(world), key=lambda q: (load[q], q))
+        out[r].append(i); load[r] += costs[i]
+    return out
+
+
+class _SharedCounter:
+    """next() hands out 0, 1, 2, ... exactly once across all ranks and threads: an atomic add on the process group's store."""
+
+    def __init__(self, dist, key):
+        from torch.distributed import distributed_c10d as c10d
+        self.store = c10d._get_default_store()
+        self.key = key
+        self.lock = threading.Lock()
+
+    def next(self):
+        with self.lock:                              # one outstanding request per process (the store client is not re-entrant)
+            return int(self.store.add(self.key, 1)) - 1
+
+
+class _LocalCounter:
+    def __init__(self):
+        self.v = 0; self.lock = threading.Lock()
+
+    def next(self):
+        with self.lock:
+            v = self.v; self.v += 1
+            return v
+
+
+def pack_record(pair_id, res, rmsd=float("nan"), rank=0):
     r = np.full(REC, np.nan, np.float64)
     r[0] = pair_id; r[1:10] = np.asarray(res["R"]).reshape(9); r[10:13] = res["t"]; r[13] = res["error"]; r[14] = res["compat"]
     r[15] = res["Nd"]; r[16] = res["seconds"]; r[17] = res.get("dt_seconds", np.nan); r[18] = res.get("cube_evals", np.nan); r[19] = rmsd
-    r[20] = res.get("status", 0)
+    r[20] = res.get("status", 0); r[21] = rank
     return r
 
 
 def gather_records(local_records, n_total, dist=None, device=None):
-    """all_gather of per-rank record blocks padded to the same length; returns [n_total, REC] ordered by pair id."""
+    """all_gather of the per-rank record blocks; returns [n_registered, REC] ordered by pair id. Under dynamic scheduling a rank may
+    hold any number of records, so the blocks are padded to n_total rows (383 x 24 doubles = 74 KB per rank: latency-bound, one
+    collective)."""
     import torch
     world = dist.get_world_size() if dist is not None and dist.is_initialized() else 1
-    per = (n_total + world - 1) // world
+    per = max(int(n_total), len(local_records), 1)
     block = np.full((per, REC), np.nan, np.float64)
     for i, r in enumerate(local_records):
         block[i] = r
@@ -64,29 +115,129 @@ def gather_records(local_records, n_total, dist=None, device=None):
     return allb[order]
 
 
-def run_batch(base_dir, tsv, config, out_dir, register_fn, rank=0, world=1, limit=None, threads=1):
-    """register_fn(target_file, source_file, nd, config, output, k) -> result dict. Pairs whose cavity files are
-    missing are skipped (the reference tree ships 2 of the 383). threads > 1 keeps that many registrations of this rank in
-    flight (one engine + HIP stream each; the C entry points release the GIL); records come back in row order either way."""
+def protein_paths(base_dir, src, tgt):
+    """Files of the protein stage (reference layout: chains/, ref_proteins/<src>.<tgt>/, rot/ -- jly_main.cpp:159-172 (disabled
+    there), README.md:20-25); None where the inputs are absent."""
+    chain = os.path.join(base_dir, "chains", src + "_protein.mol2")
+    aligned = os.path.join(base_dir, "ref_proteins", "%s.%s" % (src, tgt), "aligned_%s_protein.mol2" % src)
+    if not (os.path.exists(chain) and os.path.exists(aligned)):
+        return None
+    os.makedirs(os.path.join(base_dir, "rot"), exist_ok=True)
+    return chain, aligned, os.path.join(base_dir, "rot", "rot_%s_protein.mol2" % src)
+
+
+def pair_rmsd(base_dir, src, tgt, output):
+    """RMSD of the registration just written to `output`: the source protein is transformed with the rescaled R, t of THIS run
+    (Transformation::applyTransformationProtein, reference transformation.cpp:469-539) and compared with the aligned reference
+    protein (Transformation::computeRMSD, :453-464). NaN when the protein files do not exist."""
+    from . import binding
+    pp = protein_paths(base_dir, src, tgt)
+    if pp is None:
+        return float("nan")
+    chain, aligned, rot = pp
+    resc = output[:output.find(".")] + "_rescaled.txt"      # the name the pipeline writes: cut at the FIRST '.' (transformation.cpp:405)
+    if not os.path.exists(resc) or not binding.apply_transformation_protein(resc, chain, rot):
+        return float("nan")
+    return binding.compute_rmsd(aligned, rot)
+
+
+def gpu_register_fn(base_dir, device_id=0):
+    """The registration the batch runs per row: the reference's main() on files through the C ABI (goicp_run_pair_files)."""
+    from . import binding
+
+    def reg(tf, sf, nd, config, output, k):
+        return binding.run_pair_files(base_dir, tf, sf, nd, config, output, k, device_id=device_id)
+    return reg
+
+
+def list_jobs(base_dir, tsv, limit=None):
+    """(k, target file, source file, Nd, cost proxy, src id, tgt id) for every row whose cavity files exist (the reference tree
+    ships 2 of the 383); k = 1-based row number = the reference's pair number."""
     pairs = read_tsv_pairs(tsv)
     if limit:
         pairs = pairs[:limit]
-    todo = []
-    for idx in shard(len(pairs), rank, world):
-        src, tgt = pairs[idx]
-        k = idx + 1
+    jobs = []
+    for idx, (src, tgt) in enumerate(pairs):
         sf = os.path.join("cavities", src + "_cavity6.mol2"); tf = os.path.join("cavities", tgt + "_cavity6.mol2")
         if not (os.path.exists(os.path.join(base_dir, sf)) and os.path.exists(os.path.join(base_dir, tf))):
             continue
-        todo.append((k, tf, sf, mol2_atom_count(os.path.join(base_dir, sf))))
+        nd = mol2_atom_count(os.path.join(base_dir, sf)); nm = mol2_atom_count(os.path.join(base_dir, tf))
+        jobs.append((idx + 1, tf, sf, nd, float(nd) * float(nm), src, tgt))
+    return jobs, len(pairs)
+
+
+def run_batch(base_dir, tsv, config, out_dir, register_fn, rank=0, world=1, limit=None, threads=1, schedule=None, dist=None, rmsd=True,
+              counter_key="goicp_batch_next"):
+    """register_fn(target_file, source_file, nd, config, output, k) -> result dict. Rows whose cavity files are missing are
+    skipped. threads > 1 keeps that many registrations of this rank in flight (one engine + HIP stream each; the C entry points
+    release the GIL). Returns (records of this rank in the order they were taken, number of rows)."""
+    jobs, n_rows = list_jobs(base_dir, tsv, limit)
+    costs = [j[4] for j in jobs]
+    have_pg = dist is not None and dist.is_initialized() and dist.get_world_size() > 1
+    if schedule is None:
+        schedule = "dynamic" if (have_pg or world == 1) else "lpt"
+    order = lpt_order(costs)
+    counter = None
+    if schedule == "dynamic":
+        if have_pg:
+            try:
+                counter = _SharedCounter(dist, counter_key)
+            except Exception:
+                schedule = "lpt"                    # no store access: static longest-first partition instead
+        elif world == 1:
+            counter = _LocalCounter()
+        else:
+            schedule = "lpt"
+    if schedule == "lpt":
+        mine = lpt_assign(costs, world)[rank]
+    elif schedule == "rr":
+        mine = shard(len(jobs), rank, world)
+    else:
+        mine = None
+    os.makedirs(out_dir, exist_ok=True)
 
     def one(job):
-        k, tf, sf, nd = job
-        return pack_record(k, register_fn(tf, sf, nd, config, os.path.join(out_dir, "similar%d.txt" % k), k))
-    if threads > 1 and len(todo) > 1:
-        from concurrent.futures import ThreadPoolExecutor
-        with ThreadPoolExecutor(max_workers=threads) as ex:
-            recs = list(ex.map(one, todo))
+        k, tf, sf, nd, _, src, tgt = job
+        output = os.path.join(out_dir, "similar%d.txt" % k)
+        res = register_fn(tf, sf, nd, config, output, k)
+        val = pair_rmsd(base_dir, src, tgt, output) if (rmsd and int(res.get("status", 0)) == 0) else float("nan")
+        return pack_record(k, res, rmsd=val, rank=rank)
+
+    recs = []; lock = threading.Lock()
+    if mine is not None:
+        local = _LocalCounter()
+
+        def take():
+            i = local.next()
+            return mine[i] if i < len(mine) else None
     else:
-        recs = [one(j) for j in todo]
-    return recs, len(pairs)
+        def take():
+            i = counter.next()
+            return order[i] if i < len(order) else None
+
+    errors = []
+
+    def worker():
+        try:
+            while not errors:
+                j = take()
+                if j is None:
+                    return
+                r = one(jobs[j])
+                with lock:
+                    recs.append(r)
+        except BaseException as e:                  # surfaced after the join: a failed registration must not pass silently
+            errors.append(e)
+    nthreads = max(1, int(threads))
+    if nthreads > 1:
+        ts = [threading.Thread(target=worker) for _ in range(nthreads)]
+        for t in ts:
+            t.start()
+        for t in ts:
+            t.join()
+    else:
+        worker()
+    if errors:
+        raise errors[0]
+    recs.sort(key=lambda r: r[0])
+    return recs, n_rows

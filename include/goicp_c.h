@@ -46,6 +46,12 @@ void goicp_set_init_trans(goicp_handle*, float x, float y, float z, float w, flo
 
 /* GoICP::ICP (reference jly_goicp.cpp:102-178); R9/t3 in-out; corr[Nd*2]=(id_data,id_model) or NULL */
 float goicp_icp(goicp_handle*, double* R9, double* t3, int32_t* corr);
+/* POINTREF::dis of that run (reference jly_icp3d.hpp:80-85,247), same order as corr; returns the count written */
+int goicp_icp_distances(goicp_handle*, double* dis);
+/* host-side restatement of the reference kd-tree's 1-NN visiting order (nanoflann 1.1.6 as built by ICP3D::Build, reference
+ * jly_icp3d.hpp:141-169, nanoflann.hpp:927-1184): the model index knnSearch(q,1) returns, exact distance ties included. GoICP::ICP
+ * consults it only for queries whose device search reports a tie (goicp_engine_icp_nn_ties). Pure host code. */
+int goicp_kdorder_nn(const float* model_xyz, int Nm, const float* queries_xyz, int n, int32_t* id_model, float* dist_sq);
 /* GoICP::Register. out16: optR[9], optT[3], optError, optComp, Nd, inlierNum. Returns optError (NaN on failure). */
 float goicp_register(goicp_handle*, double* out16);
 int goicp_status(goicp_handle*);

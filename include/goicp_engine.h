@@ -134,6 +134,11 @@ int goicp_engine_inner_bnb_batch(goicp_engine* h, const goicp_bnb_job* jobs, int
 int goicp_engine_point_eval(goicp_engine* h, const double* R9, const double* t3, float* dist, int32_t* compat);
 /* q_i = R*p_i + t in float (R,t rounded from double); nearest model point id and squared distance */
 int goicp_engine_icp_nn(goicp_engine* h, const double* R9, const double* t3, int32_t* id_model, float* dist_sq);
+/* the same search (kdtree->knnSearch(query, 1, ...), reference jly_icp3d.hpp:245) plus n_tied[i] = number of model points at
+ * exactly the minimal float distance of query i (id_model[i] is then the lowest of them). The reference's kd-tree keeps the
+ * first such point it visits (reference nanoflann.hpp:1137-1184); the host-side GoICP::ICP resolves those queries with its
+ * restatement of that visiting order (csrc/host_kdorder.hpp). */
+int goicp_engine_icp_nn_ties(goicp_engine* h, const double* R9, const double* t3, int32_t* id_model, float* dist_sq, int32_t* n_tied);
 
 int goicp_engine_synchronize(goicp_engine* h);
 /* cumulative counters since create: cube evaluations, point lookups, kernel milliseconds (HIP events) */

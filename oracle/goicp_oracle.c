@@ -4,6 +4,7 @@
  * Build: gcc -O2 -ffp-contract=off (oracle/Makefile); no FMA, float expressions evaluated in float.
  */
 #include "goicp_oracle.h"
+#include <float.h>
 #include <math.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -741,6 +742,137 @@ void orc_svd3_rot(const double* H, double* Rout) {
     mat3_mul(V, D, VD); mat3_mul(VD, Ut, Rout);
 }
 
+/* ---------------------------------------------------------------------------------------------
+ * 1-NN with the search ORDER of the reference's kd-tree (vendored nanoflann 1.1.6: KDTreeSingleIndexAdaptor<
+ * L2_Simple_Adaptor<float>, PointCloud<float>, 3>, leaf size 10, built by ICP3D::Build, jly_icp3d.hpp:141-169).
+ * Restated because the result of an exact search still depends on the traversal: a candidate replaces the current best only
+ * if it is strictly closer (KNNResultSet::addPoint, nanoflann.hpp:95-116; leaf test :1147), so among model points at exactly
+ * the same float distance the one met first wins, and subtrees are pruned with float-accumulated box distances
+ * (nanoflann.hpp:1137-1184). Tree construction: divideTree/middleSplit_/planeSplit (nanoflann.hpp:927-1110), including
+ * middleSplit_'s habit of measuring the spread of the axis chosen so far rather than of the axis under test (:1047).
+ * ------------------------------------------------------------------------------------------- */
+typedef struct { int c1, c2; int left, right; int feat; float divlow, divhigh; } kdnode;   /* c1 < 0: leaf over vind[left, right) */
+typedef struct { const float* pts; int n; int* vind; kdnode* nodes; int nn, cap; float lo[3], hi[3]; int root; } kdtree;
+
+static void kd_minmax(const kdtree* T, const int* ind, long count, int f, float* mn, float* mx) {
+    *mn = *mx = T->pts[3 * ind[0] + f];
+    for (long i = 1; i < count; i++) { float v = T->pts[3 * ind[i] + f]; if (v < *mn) *mn = v; if (v > *mx) *mx = v; }
+}
+static void kd_plane_split(const kdtree* T, int* ind, long count, int f, float cutval, long* lim1, long* lim2) {
+    long left = 0, right = count - 1; int t;
+    for (;;) {
+        while (left <= right && T->pts[3 * ind[left] + f] < cutval) ++left;
+        while (right && left <= right && T->pts[3 * ind[right] + f] >= cutval) --right;
+        if (left > right || !right) break;
+        t = ind[left]; ind[left] = ind[right]; ind[right] = t; ++left; --right;
+    }
+    *lim1 = left; right = count - 1;
+    for (;;) {
+        while (left <= right && T->pts[3 * ind[left] + f] <= cutval) ++left;
+        while (right && left <= right && T->pts[3 * ind[right] + f] > cutval) --right;
+        if (left > right || !right) break;
+        t = ind[left]; ind[left] = ind[right]; ind[right] = t; ++left; --right;
+    }
+    *lim2 = left;
+}
+static int kd_divide(kdtree* T, long left, long right, float* lo, float* hi) {
+    if (T->nn == T->cap) { T->cap = 2 * T->cap + 16; T->nodes = (kdnode*)realloc(T->nodes, sizeof(kdnode) * T->cap); }
+    int me = T->nn++;
+    if (right - left <= 10) {
+        T->nodes[me].c1 = T->nodes[me].c2 = -1; T->nodes[me].left = (int)left; T->nodes[me].right = (int)right;
+        for (int i = 0; i < 3; i++) lo[i] = hi[i] = T->pts[3 * T->vind[left] + i];
+        for (long k = left + 1; k < right; k++) for (int i = 0; i < 3; i++) {
+            float v = T->pts[3 * T->vind[k] + i];
+            if (lo[i] > v) lo[i] = v;
+            if (hi[i] < v) hi[i] = v;
+        }
+        return me;
+    }
+    int* ind = T->vind + left; long count = right - left;
+    const float EPS = 0.00001f;
+    float max_span = hi[0] - lo[0];
+    for (int i = 1; i < 3; i++) { float span = hi[i] - lo[i]; if (span > max_span) max_span = span; }
+    float max_spread = -1; int cutfeat = 0; float mn, mx;
+    for (int i = 0; i < 3; i++) {
+        float span = hi[i] - lo[i];
+        if (span > (1 - EPS) * max_span) {
+            kd_minmax(T, ind, count, cutfeat, &mn, &mx);           /* sic: the axis chosen so far */
+            float spread = mx - mn;
+            if (spread > max_spread) { cutfeat = i; max_spread = spread; }
+        }
+    }
+    float split_val = (lo[cutfeat] + hi[cutfeat]) / 2, cutval;
+    kd_minmax(T, ind, count, cutfeat, &mn, &mx);
+    if (split_val < mn) cutval = mn; else if (split_val > mx) cutval = mx; else cutval = split_val;
+    long lim1, lim2, idx;
+    kd_plane_split(T, ind, count, cutfeat, cutval, &lim1, &lim2);
+    if (lim1 > count / 2) idx = lim1; else if (lim2 < count / 2) idx = lim2; else idx = count / 2;
+    float llo[3], lhi[3], rlo[3], rhi[3];
+    memcpy(llo, lo, sizeof llo); memcpy(lhi, hi, sizeof lhi); memcpy(rlo, lo, sizeof rlo); memcpy(rhi, hi, sizeof rhi);
+    lhi[cutfeat] = cutval;
+    int c1 = kd_divide(T, left, left + idx, llo, lhi);
+    rlo[cutfeat] = cutval;
+    int c2 = kd_divide(T, left + idx, right, rlo, rhi);
+    kdnode* nd = &T->nodes[me];
+    nd->c1 = c1; nd->c2 = c2; nd->feat = cutfeat; nd->divlow = lhi[cutfeat]; nd->divhigh = rlo[cutfeat];
+    for (int i = 0; i < 3; i++) { lo[i] = llo[i] < rlo[i] ? llo[i] : rlo[i]; hi[i] = lhi[i] > rhi[i] ? lhi[i] : rhi[i]; }
+    return me;
+}
+static kdtree* kd_build(const float* pts, int n) {
+    kdtree* T = (kdtree*)calloc(1, sizeof *T);
+    T->pts = pts; T->n = n; T->vind = (int*)malloc(sizeof(int) * (n > 0 ? n : 1));
+    for (int i = 0; i < n; i++) T->vind[i] = i;
+    T->root = -1;
+    if (n <= 0) return T;
+    for (int i = 0; i < 3; i++) T->lo[i] = T->hi[i] = pts[i];       /* computeBoundingBox, nanoflann.hpp:894-917 */
+    for (int k = 1; k < n; k++) for (int i = 0; i < 3; i++) { float v = pts[3 * k + i]; if (v < T->lo[i]) T->lo[i] = v; if (v > T->hi[i]) T->hi[i] = v; }
+    T->root = kd_divide(T, 0, n, T->lo, T->hi);
+    return T;
+}
+static void kd_free(kdtree* T) { if (T) { free(T->vind); free(T->nodes); free(T); } }
+typedef struct { float best; int idx; } kdres;
+static void kd_search(const kdtree* T, kdres* r, const float* q, int node, float mindistsq, float* dists) {
+    const kdnode* nd = &T->nodes[node];
+    if (nd->c1 < 0) {
+        const float worst = r->best;
+        for (int i = nd->left; i < nd->right; i++) {
+            const int m = T->vind[i];
+            const float d0 = q[0] - T->pts[3 * m], d1 = q[1] - T->pts[3 * m + 1], d2 = q[2] - T->pts[3 * m + 2];
+            const float d = d0 * d0 + d1 * d1 + d2 * d2;
+            if (d < worst && r->best > d) { r->best = d; r->idx = m; }
+        }
+        return;
+    }
+    const int f = nd->feat; const float val = q[f];
+    const float diff1 = val - nd->divlow, diff2 = val - nd->divhigh;
+    int bestc, otherc; float cut;
+    if ((diff1 + diff2) < 0) { bestc = nd->c1; otherc = nd->c2; cut = (val - nd->divhigh) * (val - nd->divhigh); }
+    else { bestc = nd->c2; otherc = nd->c1; cut = (val - nd->divlow) * (val - nd->divlow); }
+    kd_search(T, r, q, bestc, mindistsq, dists);
+    const float dst = dists[f];
+    mindistsq = mindistsq + cut - dst;
+    dists[f] = cut;
+    if (mindistsq * 1.0f <= r->best) kd_search(T, r, q, otherc, mindistsq, dists);
+    dists[f] = dst;
+}
+static int kd_nn(const kdtree* T, const float* q, float* dist_out) {
+    kdres r; r.best = FLT_MAX; r.idx = 0;
+    float dists[3] = {0, 0, 0}, distsq = 0;
+    for (int i = 0; i < 3; i++) {                                    /* computeInitialDistances, nanoflann.hpp:1113-1131 */
+        if (q[i] < T->lo[i]) { dists[i] = (q[i] - T->lo[i]) * (q[i] - T->lo[i]); distsq += dists[i]; }
+        if (q[i] > T->hi[i]) { dists[i] = (q[i] - T->hi[i]) * (q[i] - T->hi[i]); distsq += dists[i]; }
+    }
+    if (T->root >= 0) kd_search(T, &r, q, T->root, distsq, dists);
+    *dist_out = r.best;
+    return r.idx;
+}
+/* test hook: the tree's 1-NN for n query points */
+void orc_kd_nn(const float* model, int Nm, const float* q, int n, int* id, float* d) {
+    kdtree* T = kd_build(model, Nm);
+    for (int i = 0; i < n; i++) id[i] = kd_nn(T, q + 3 * i, &d[i]);
+    kd_free(T);
+}
+
 typedef struct { double dis; int id_data, id_model; } pref;
 
 static void stable_sort_dis(pref* p, pref* tmp, int n) {   /* qsort+cmp of jly_icp3d.hpp:172-176,254 under glibc (merge sort, ties keep order) */
@@ -756,10 +888,11 @@ static void stable_sort_dis(pref* p, pref* tmp, int n) {   /* qsort+cmp of jly_i
     }
 }
 
-/* ICP3D<float>::Run, jly_icp3d.hpp:197-311 (1-NN by exhaustive search; exact ties -> lowest model index) */
+/* ICP3D<float>::Run, jly_icp3d.hpp:197-311 (1-NN through the kd-tree restatement above: the reference's visiting order) */
 static float icp_run(orc_ctx* c, double* R, double* t) {
-    int n = c->Nd, Nm = c->Nm, num, i;
+    int n = c->Nd, num, i;
     const float* data = c->dxyz; const float* model = c->mxyz;
+    kdtree* kd = kd_build(model, c->Nm);          /* icp3d.Build(M_icp, Nm), jly_goicp.cpp:231 (the tree is a pure function of the model) */
     float err_diff = c->MSEThresh / 10000;
     if (c->doTrim) num = (int)(n * (1 - c->trimFraction)); else num = n;
     pref* pts = (pref*)malloc(sizeof(pref) * n); pref* tmp = (pref*)malloc(sizeof(pref) * n);
@@ -774,12 +907,8 @@ static float icp_run(orc_ctx* c, double* R, double* t) {
             float q0 = r00 * data[3*i] + r01 * data[3*i+1] + r02 * data[3*i+2] + t0;
             float q1 = r10 * data[3*i] + r11 * data[3*i+1] + r12 * data[3*i+2] + t1;
             float q2 = r20 * data[3*i] + r21 * data[3*i+1] + r22 * data[3*i+2] + t2;
-            float best = INFINITY; int bi = 0;
-            for (int m = 0; m < Nm; m++) {
-                float d0 = q0 - model[3*m], d1 = q1 - model[3*m+1], d2 = q2 - model[3*m+2];
-                float d = d0 * d0 + d1 * d1 + d2 * d2;
-                if (d < best) { best = d; bi = m; }
-            }
+            float qv[3] = {q0, q1, q2}, best;
+            int bi = kd_nn(kd, qv, &best);                      /* kdtree->knnSearch(query, 1, ...), jly_icp3d.hpp:245 */
             pts[i].dis = best; pts[i].id_data = i; pts[i].id_model = bi;
         }
         if (c->doTrim) stable_sort_dis(pts, tmp, n);
@@ -811,7 +940,7 @@ static float icp_run(orc_ctx* c, double* R, double* t) {
         memcpy(R, Rc, sizeof Rc); memcpy(t, tc, sizeof tc);
     }
     for (i = 0; i < n; i++) { c->icp_pts[2*i] = pts[i].id_data; c->icp_pts[2*i+1] = pts[i].id_model; c->icp_dis[i] = pts[i].dis; }
-    free(pts); free(tmp); free(p_m); free(p_d);
+    free(pts); free(tmp); free(p_m); free(p_d); kd_free(kd);
     return err_new;
 }
 

@@ -57,6 +57,8 @@ float orc_inner_bnb(orc_ctx*, int level, float* node_out6, int want_node);   /* 
 int   orc_check_compatibilities(orc_ctx*, float x, float y, float z);        /* jly_goicp.cpp:919-928 */
 float orc_sum_fpfh(orc_ctx*, float x, float y, float z);                     /* jly_goicp.cpp:1689-1697 */
 float orc_icp(orc_ctx*, double* R9, double* t3, int* corr, double* dis);     /* jly_goicp.cpp:102-178 */
+/* 1-NN of n queries in the visiting order of the reference's kd-tree (nanoflann.hpp:927-1184, jly_icp3d.hpp:141-169) */
+void orc_kd_nn(const float* model_xyz, int Nm, const float* queries_xyz, int n, int* id_model, float* dist_sq);
 float orc_register(orc_ctx*, double* out16);                                 /* jly_goicp.cpp:878-885 */
 int   orc_last_log(orc_ctx*, char* buf, int cap);
 

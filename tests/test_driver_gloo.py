@@ -31,35 +31,109 @@ def test_shard_is_a_partition():
 
 
 def _fake_register(tf, sf, nd, config, output, k):
-    # deterministic stand-in for the GPU registration: the driver logic under test is sharding + gather
+    # deterministic stand-in for the GPU registration: the driver logic under test is scheduling + gather
     R = np.eye(3) * k
     return dict(R=R, t=np.array([k, k + 1, k + 2], float), error=10.0 * k, compat=nd, Nd=nd, seconds=0.01 * k, dt_seconds=0.0, cube_evals=100 * k, status=0)
 
 
-def _worker(rank, world, port, tmp):
+def test_lpt_assignment_is_a_balanced_partition():
+    rng = np.random.default_rng(3)
+    costs = list(rng.integers(150, 401, 383) * rng.integers(150, 401, 383).astype(float))
+    for world in (1, 2, 3, 8):
+        parts = driver.lpt_assign(costs, world)
+        assert sorted(sum(parts, [])) == list(range(383))
+        loads = [sum(costs[i] for i in p) for p in parts]
+        assert max(loads) - min(loads) <= max(costs)                   # greedy LPT: no rank exceeds another by more than one item
+        for p in parts:
+            assert [costs[i] for i in p] == sorted((costs[i] for i in p), reverse=True)   # longest first inside a rank
+    assert driver.lpt_order([5.0, 9.0, 5.0, 1.0]) == [1, 0, 2, 3]
+
+
+@pytest.fixture(scope="module")
+def small_batch(tmp_path_factory):
+    """14 rows of the configs[3] batch (2 real + 12 synthetic cavity pairs) as files."""
+    d = str(tmp_path_factory.mktemp("c4"))
+    tsv, cfgp, truth = goicp_amd.c4_batch.materialise(d, DATA, rows=14)
+    return d, tsv, cfgp, truth
+
+
+def test_c4_batch_files_are_readable_and_consistent(small_batch):
+    from oracle.refbind import read_mol2, read_cfpfh, read_config
+    d, tsv, cfgp, truth = small_batch
+    jobs, n = driver.list_jobs(d, tsv)
+    assert n == 14 and [j[0] for j in jobs] == list(range(1, 15))
+    assert jobs[0][5:] == ("2x86_3", "1eq2_6") and jobs[0][3] == 238 and jobs[1][3] == 247
+    cfg = read_config(cfgp)
+    assert cfg["cfpfh"] == 1 and abs(cfg["regularizationFPFH"] - 5e-6) < 1e-12 and cfg["regularization"] == 0.0005 and cfg["distTransSize"] == 20
+    for k, tf, sf, nd, cost, src, tgt in jobs[2:]:
+        sx, sc = read_mol2(os.path.join(d, sf)); tx, tc = read_mol2(os.path.join(d, tf))
+        assert len(sx) == nd and 150 <= nd <= 400 and cost == float(len(sx)) * len(tx)
+        assert read_cfpfh(os.path.join(d, "cfpfh", src + "_cavity6.cfpfh"), nd).shape == (nd, 41)
+        R, t = truth[k - 1]
+        # the planted pose maps most source atoms (the inliers) onto the target cloud
+        moved = sx @ R.T + t
+        nn = np.sqrt(((moved[:, None, :] - tx[None, :, :]) ** 2).sum(-1)).min(1)
+        assert np.median(nn) < 0.6                                   # Angstrom; noise 0.01 x scale 9-14
+        assert driver.protein_paths(d, src, tgt) is not None
+    assert driver.protein_paths(d, "2x86_3", "1eq2_6") is not None and driver.protein_paths(d, "2ktd_1", "4imo_2") is not None
+
+
+def test_pair_rmsd_of_the_planted_pose_is_zero(small_batch, tmp_path):
+    """The RMSD slot of a record: protein transformed with the run's rescaled R, t (applyTransformationProtein) against the aligned
+    reference protein (computeRMSD); feeding the planted pose must give ~0 (4-decimal file rounding)."""
+    d, tsv, cfgp, truth = small_batch
+    jobs, _ = driver.list_jobs(d, tsv)
+    k, tf, sf, nd, cost, src, tgt = jobs[5]
+    R, t = truth[k - 1]
+    out = os.path.join(str(tmp_path).replace(".", "_"), "similar%d.txt" % k); os.makedirs(os.path.dirname(out), exist_ok=True)
+    with open(out[:out.find(".")] + "_rescaled.txt", "w") as f:
+        f.write("Time: 0\nRotation Matrix:\n" + "\n".join("   %.9g   %.9g   %.9g" % tuple(r) for r in R) + "\nTranslation Vector:\n" + "\n".join("   %.9g" % v for v in t) + "\nError: 0\n")
+    assert driver.pair_rmsd(d, src, tgt, out) < 2e-3
+    assert np.isnan(driver.pair_rmsd(d, "nosuch", tgt, out))
+
+
+def _slow_fake_register(tf, sf, nd, config, output, k):
+    import time
+    time.sleep(0.002 * (nd % 7))
+    return _fake_register(tf, sf, nd, config, output, k)
+
+
+def _worker(rank, world, port, tmp, base, tsv, schedule):
     os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
-    recs, n_total = driver.run_batch(DATA, os.path.join(DATA, "cavities_similar_BO1_clean.tsv"), "unused", tmp, _fake_register, rank=rank, world=world)
+    recs, n_total = driver.run_batch(base, tsv, "unused", os.path.join(tmp, "out%d" % rank), _slow_fake_register, rank=rank, world=world, threads=2,
+                                     schedule=schedule, dist=dist, counter_key="next_" + schedule)
     allr = driver.gather_records(recs, n_total, dist=dist)
     if rank == 0:
-        np.save(os.path.join(tmp, "gathered.npy"), allr)
-    np.save(os.path.join(tmp, "local_%d.npy" % rank), np.array(recs))
+        np.save(os.path.join(tmp, "gathered_%s.npy" % schedule), allr)
+    np.save(os.path.join(tmp, "local_%s_%d.npy" % (schedule, rank)), np.array(recs).reshape(-1, driver.REC))
     dist.barrier()
     dist.destroy_process_group()
 
 
-def test_two_rank_gloo_gather(tmp_path):
+@pytest.mark.parametrize("schedule", ["dynamic", "lpt", "rr"])
+def test_two_rank_gloo_batch(tmp_path, small_batch, schedule):
+    """world_size 2 over gloo: every row registered exactly once whatever the scheduler, one all_gather, records ordered by pair id."""
+    base, tsv, cfgp, truth = small_batch
     world = 2
-    port = 29500 + (os.getpid() % 2000)
-    mp.spawn(_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
-    allr = np.load(os.path.join(str(tmp_path), "gathered.npy"))
-    # only rows 1 and 2 of the tsv have their cavity files in the tree: rank 0 registers pair 1, rank 1 pair 2
-    assert allr.shape == (2, driver.REC)
-    assert list(allr[:, 0]) == [1.0, 2.0]
+    port = 29500 + (os.getpid() % 2000) + {"dynamic": 0, "lpt": 1, "rr": 2}[schedule]
+    mp.spawn(_worker, args=(world, port, str(tmp_path), base, tsv, schedule), nprocs=world, join=True)
+    allr = np.load(os.path.join(str(tmp_path), "gathered_%s.npy" % schedule))
+    assert allr.shape == (14, driver.REC)
+    assert list(allr[:, 0]) == [float(k) for k in range(1, 15)]
     assert allr[0, 15] == 238 and allr[1, 15] == 247            # Nd read from line 6 of the source mol2
     assert allr[1, 13] == 20.0 and np.array_equal(allr[1, 10:13], [2, 3, 4])
-    l0 = np.load(os.path.join(str(tmp_path), "local_0.npy")); l1 = np.load(os.path.join(str(tmp_path), "local_1.npy"))
-    assert l0.shape[0] == 1 and l1.shape[0] == 1 and l0[0, 0] == 1 and l1[0, 0] == 2
+    l0 = np.load(os.path.join(str(tmp_path), "local_%s_0.npy" % schedule)); l1 = np.load(os.path.join(str(tmp_path), "local_%s_1.npy" % schedule))
+    assert len(l0) + len(l1) == 14 and not set(l0[:, 0]) & set(l1[:, 0])
+    assert set(l0[:, 21]) <= {0.0} and set(l1[:, 21]) <= {1.0}
+    jobs, _ = driver.list_jobs(base, tsv)
+    if schedule == "lpt":
+        parts = driver.lpt_assign([j[4] for j in jobs], world)
+        assert sorted(l0[:, 0]) == sorted(jobs[i][0] for i in parts[0]) and sorted(l1[:, 0]) == sorted(jobs[i][0] for i in parts[1])
+    if schedule == "rr":
+        assert sorted(l0[:, 0]) == [1, 3, 5, 7, 9, 11, 13]
+    if schedule == "dynamic":
+        assert len(l0) >= 1 and len(l1) >= 1                    # both ranks pulled work from the shared counter
 
 
 def test_library_exports_every_declared_symbol():
@@ -93,7 +167,7 @@ def test_engine_fails_loudly_without_gpu():
 def test_threaded_batch_returns_the_same_records_in_row_order(tmp_path):
     """run_batch(threads=N) keeps N registrations of a rank in flight; the records must equal the sequential run's, in row order."""
     tsv = os.path.join(DATA, "cavities_similar_BO1_clean.tsv")
-    seq, n1 = driver.run_batch(DATA, tsv, "unused", str(tmp_path), _fake_register)
-    par, n2 = driver.run_batch(DATA, tsv, "unused", str(tmp_path), _fake_register, threads=4)
+    seq, n1 = driver.run_batch(DATA, tsv, "unused", str(tmp_path), _fake_register, rmsd=False)
+    par, n2 = driver.run_batch(DATA, tsv, "unused", str(tmp_path), _fake_register, threads=4, rmsd=False)
     assert n1 == n2 == 383 and len(seq) == len(par) == 2
     assert all(np.array_equal(a, b, equal_nan=True) for a, b in zip(seq, par))

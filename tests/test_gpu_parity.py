@@ -34,6 +34,17 @@ def engine_from_hotpath(H, P, parity=1):
 HOT = ["pair1_default", "pair1_trim", "pair1_fpfh", "pair1_norm1", "pair2_S50"]
 
 
+def oracle_kd_nn(model, q):
+    """1-NN of float queries in the reference kd-tree's visiting order (oracle/goicp_oracle.c: orc_kd_nn)."""
+    import ctypes as C
+    from oracle import refbind
+    O = C.CDLL(refbind.ORACLE_SO)
+    m = np.ascontiguousarray(model, np.float32); q = np.ascontiguousarray(q, np.float32)
+    ids = np.zeros(len(q), np.int32); d = np.zeros(len(q), np.float32)
+    O.orc_kd_nn(m.ctypes.data_as(C.c_void_p), len(m), q.ctypes.data_as(C.c_void_p), len(q), ids.ctypes.data_as(C.c_void_p), d.ctypes.data_as(C.c_void_p))
+    return ids, d
+
+
 def close(a, b, exact, n=None):
     """exact: bitwise. Otherwise the GPU sums in fp64 while the reference accumulates sequentially in float, whose own
     a-priori error bound is n*2^-24 relative; the comparison tolerance is max(1e-5, n*2^-24)."""
@@ -109,14 +120,49 @@ def test_point_eval_and_icp_nn_against_oracle():
         s = P["s"].astype(np.float32)
         q = np.stack([(R[a, 0] * s[:, 0].astype(np.float64) + R[a, 1] * s[:, 1] + R[a, 2] * s[:, 2] + t[a]).astype(np.float32) for a in range(3)], 1)
         assert np.array_equal(dist, o.distance(q.astype(np.float64)))
-        ids, d = e.icp_nn(R, t)
+        # 1-NN: exact distances; ids against the oracle's restatement of the reference kd-tree's visiting order
+        ids, d, nt = e.icp_nn(R, t, ties=True)
         Rf = R.astype(np.float32); tf = t.astype(np.float32)
         qf = np.stack([((Rf[a, 0] * s[:, 0] + Rf[a, 1] * s[:, 1]) + Rf[a, 2] * s[:, 2]) + tf[a] for a in range(3)], 1).astype(np.float32)
+        oid, od = oracle_kd_nn(P["t"], qf)
+        assert np.array_equal(d, od)
+        assert np.array_equal(ids[nt == 1], oid[nt == 1])          # untied queries: one possible answer
         m = P["t"].astype(np.float32)
         dd = qf[:, None, :] - m[None, :, :]
         d2 = ((dd[..., 0] * dd[..., 0] + dd[..., 1] * dd[..., 1]) + dd[..., 2] * dd[..., 2]).astype(np.float32)
-        assert np.array_equal(ids, d2.argmin(1)) and np.array_equal(d, d2.min(1))
+        assert np.array_equal(nt, (d2 == d2.min(1, keepdims=True)).sum(1))
     e.close()
+
+
+@pytest.mark.parametrize("name", ["pair1_default", "pair1_trim", "pair1_fpfh"])
+def test_icp_against_reference_fixtures(name):
+    """GoICP::ICP through the C ABI (goicp_icp) on the compiled reference's in/out records (tests/golden/icp_*.npz): error,
+    correspondences and distances bit for bit, R, t to 1e-12 (own Jacobi SVD vs the reference's Golub-Kahan routine)."""
+    I = dict(np.load(os.path.join(GOLDEN, "icp_%s.npz" % name)))
+    P = load_clouds("pair1")
+    g = goicp_amd.GoICP(I["cfg"]); g.set_clouds(P["t"], P["s"], P["tc"], P["sc"], P["tf"], P["sf"]); g.build_dt(); g.initialize()
+    for k in range(len(I["err"])):
+        e, R, t, corr, dis = g.icp(I["Rin"][k], I["tin"][k])
+        assert e == I["err"][k]
+        assert np.abs(R - I["Rout"][k]).max() < 1e-12 and np.abs(t - I["tout"][k]).max() < 1e-12
+        assert np.array_equal(corr, I["corr"][k]) and np.array_equal(dis, I["dis"][k])
+    g.close()
+
+
+@pytest.mark.parametrize("name", ["plain", "trim", "geo"])
+def test_icp_tie_rule_against_reference_fixture(name):
+    """Exact distance ties (duplicated model points, lattice-midpoint queries): the device search reports them and the host
+    names the point the reference's kd-tree visits first (nanoflann.hpp:1137-1184); known answers from the compiled reference."""
+    I = dict(np.load(os.path.join(GOLDEN, "icp_ties.npz")))
+    g = goicp_amd.GoICP(I[name + "_cfg"]); g.set_clouds(I[name + "_model"], I[name + "_data"]); g.build_dt(); g.initialize()
+    ids, d, nt = g.engine().icp_nn(np.eye(3), np.zeros(3), ties=True)
+    assert (nt > 1).sum() >= 100                                   # the case really is tie-heavy
+    for k in range(len(I[name + "_err"])):
+        e, R, t, corr, dis = g.icp(I[name + "_Rin"][k], I[name + "_tin"][k])
+        assert e == I[name + "_err"][k]
+        assert np.abs(R - I[name + "_Rout"][k]).max() < 1e-12 and np.abs(t - I[name + "_tout"][k]).max() < 1e-12
+        assert np.array_equal(corr, I[name + "_corr"][k]) and np.array_equal(dis, I[name + "_dis"][k])
+    g.close()
 
 
 REG = ["pair1_default", "pair1_fpfh", "pair1_fpfh33", "pair1_color8", "pair1_norm1", "pair1_trim", "pair1_S50", "pair1_S100_geo",

@@ -89,6 +89,49 @@ def test_icp_known_answers(name):
         assert np.array_equal(dis, I["dis"][k])
 
 
+@pytest.mark.parametrize("name", ["plain", "trim", "geo"])
+def test_icp_tie_rule_known_answers(name):
+    """Exact float distance ties in the 1-NN step (duplicated model points, queries on lattice midpoints): the compiled
+    reference's correspondences (tests/golden/make_icp_ties.py) pin the kd-tree visiting order the oracle restates
+    (nanoflann.hpp:927-1184). A lowest-index rule fails this test on most rows."""
+    I = dict(np.load(os.path.join(GOLDEN, "icp_ties.npz")))
+    o = Oracle(); o.set_config(I[name + "_cfg"]); o.set_clouds(I[name + "_model"], I[name + "_data"]); o.build_dt(); o.initialize()
+    for k in range(len(I[name + "_err"])):
+        e, R, t, corr, dis = o.icp(I[name + "_Rin"][k], I[name + "_tin"][k])
+        assert e == I[name + "_err"][k]
+        assert np.abs(R - I[name + "_Rout"][k]).max() < 1e-12 and np.abs(t - I[name + "_tout"][k]).max() < 1e-12
+        assert np.array_equal(corr, I[name + "_corr"][k]) and np.array_equal(dis, I[name + "_dis"][k])
+
+
+def test_host_kdorder_equals_the_oracle_tree():
+    """csrc/host_kdorder.hpp (the product's tie-breaker, pure host code) against the oracle's restatement of the same tree, on
+    tie-heavy and on random clouds incl. leaf-sized and single-point models."""
+    import ctypes as C
+    import goicp_amd
+    from oracle import refbind
+    L = goicp_amd.load_library(); O = C.CDLL(refbind.ORACLE_SO)
+    I = dict(np.load(os.path.join(GOLDEN, "icp_ties.npz")))
+    rng = np.random.default_rng(77)
+    cases = [(I["plain_model"], I["plain_data"]), (I["trim_model"], I["trim_data"])]
+    for nm in (1, 7, 10, 11, 64, 500, 3000):
+        m = rng.uniform(-1, 1, (nm, 3)).astype(np.float32)
+        if nm >= 64:
+            m[rng.choice(nm, nm // 8)] = m[rng.choice(nm, nm // 8)]          # duplicates
+        m = (np.round(m * 16) / 16).astype(np.float32) if nm in (64, 500) else m     # coarse lattice: many ties
+        q = np.concatenate([rng.uniform(-1.2, 1.2, (300, 3)), (np.round(rng.uniform(-1, 1, (300, 3)) * 16) / 16 + 1 / 32)]).astype(np.float32)
+        cases.append((m, q))
+    for m, q in cases:
+        m = np.ascontiguousarray(m, np.float32); q = np.ascontiguousarray(q, np.float32); n = len(q)
+        a = np.zeros(n, np.int32); da = np.zeros(n, np.float32); b = np.zeros(n, np.int32); db = np.zeros(n, np.float32)
+        vp = lambda x: x.ctypes.data_as(C.c_void_p)
+        assert L.goicp_kdorder_nn(vp(m), len(m), vp(q), n, vp(a), vp(da)) == 0
+        O.orc_kd_nn(vp(m), len(m), vp(q), n, vp(b), vp(db))
+        assert np.array_equal(a, b) and np.array_equal(da, db)
+        d = q[:, None, :] - m[None, :, :]
+        d2 = ((d[..., 0] * d[..., 0] + d[..., 1] * d[..., 1]) + d[..., 2] * d[..., 2]).astype(np.float32)
+        assert np.array_equal(da, d2.min(1))                                  # the search is exact; only the tie choice is tree-dependent
+
+
 REG_FAST = ["pair1_default", "pair1_fpfh", "pair1_fpfh33", "pair1_color8", "pair1_norm1", "pair1_trim", "pair1_S50", "pair1_S100_geo"]
 
 
