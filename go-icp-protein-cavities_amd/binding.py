@@ -68,6 +68,7 @@ def load_library():
     L = C.CDLL(LIB_PATH)
     L.goicp_engine_last_error.restype = C.c_char_p
     L.goicp_engine_stream.restype = C.c_void_p
+    L.goicp_engine_eval_kernel_name.restype = C.c_char_p
     L.goicp_new.restype = C.c_void_p
     L.goicp_get_engine.restype = C.c_void_p
     L.goicp_register.restype = C.c_float
@@ -210,6 +211,9 @@ class Engine:
 
     def stream(self):
         return self.L.goicp_engine_stream(self.h)
+
+    def eval_kernel_name(self):
+        return self.L.goicp_engine_eval_kernel_name(self.h).decode()
 
     def stats(self):
         ce = C.c_uint64(); lk = C.c_uint64(); ms = C.c_double()

@@ -1584,7 +1584,7 @@ struct goicp_engine {
     int jit_bnb;                             // geometric searches of 1025..2048 points: k_inner_bnb<512, 4, false, false, true>
     unsigned max_pops;
     uint64_t n_cubes, n_lookups; double kernel_ms;
-    std::string err;
+    std::string err, kernel_name;
 };
 
 // ---------------------------------------------------------------------------------------------
@@ -2017,6 +2017,18 @@ static int launch_eval(goicp_engine* h, int slot, int rot_level, const int2* gro
     HIPCHK(h, hipGetLastError());
     h->n_cubes += (uint64_t)n * ngroups; h->n_lookups += (uint64_t)n * ngroups * h->T.Nd;
     return GOICP_OK;
+}
+
+extern "C" const char* goicp_engine_eval_kernel_name(goicp_engine* h) {
+    // the instantiation launch_eval() picks for this engine, spelled as rocprofv3 prints it
+    if (!h) return "";
+    char buf[96];
+    const bool jit = h->block == 1024 && h->ppt >= 2 && !h->T.exact && !h->T.use_compat && !h->T.use_fpfh && !(getenv("GOICP_JIT") && atoi(getenv("GOICP_JIT")) == 0);
+    if (h->streamed) snprintf(buf, sizeof buf, "k_eval_cubes_stream<%d>", h->T.Nd > 16384 ? 1024 : 512);
+    else if (jit) snprintf(buf, sizeof buf, "k_eval_cubes<512,%d,8,true>", 2 * h->ppt);
+    else snprintf(buf, sizeof buf, "k_eval_cubes<%d,%d,8,false>", h->block, h->ppt);
+    h->kernel_name = buf;
+    return h->kernel_name.c_str();
 }
 
 extern "C" int goicp_engine_eval_cubes_dev(goicp_engine* h, int slot, int rot_level, const void* cubes_dev, int n, void* ub_dev, void* lb_dev) {

@@ -143,6 +143,8 @@ int goicp_engine_icp_nn_ties(goicp_engine* h, const double* R9, const double* t3
 int goicp_engine_synchronize(goicp_engine* h);
 /* cumulative counters since create: cube evaluations, point lookups, kernel milliseconds (HIP events) */
 int goicp_engine_stats(const goicp_engine* h, uint64_t* cube_evals, uint64_t* lookups, double* kernel_ms);
+/* name of the cube-sweep kernel instantiation goicp_engine_eval_cubes* launches for this handle (as profilers print it) */
+const char* goicp_engine_eval_kernel_name(goicp_engine* h);
 /* opaque hipStream_t of the handle, for callers that time with their own HIP events */
 void* goicp_engine_stream(const goicp_engine* h);
 

@@ -135,6 +135,18 @@ def test_bench_prints_the_contract_line():
     assert abs(J["ms_per_step"] - R["avg_launch_ms"]) < 0.15 * J["ms_per_step"]
 
 
+def test_bench_refuses_more_ranks_than_gpus():
+    """bench.py --gpus N must start N ranks or fail loudly: on this one-GPU box --gpus 2 exits non-zero without a JSON line."""
+    import subprocess, sys, torch
+    if torch.cuda.device_count() >= 2:
+        pytest.skip("two GPUs visible")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--no-cpu", "--no-register"],
+                         capture_output=True, text=True, timeout=180, cwd=root)
+    assert out.returncode != 0 and "--gpus 2" in out.stderr
+    assert not [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+
+
 def test_non_finite_coordinates_are_refused_and_tiny_clouds_register():
     """NaN / inf coordinates come back as an error from set_clouds (they would walk the reference-order selection loops out
     of their arrays); degenerate but finite inputs (one point, identical points, a 2^3 grid, far outside the grid) register."""

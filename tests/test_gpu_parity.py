@@ -432,26 +432,88 @@ def test_file_pipeline_reproduces_shipped_output_files(tmp_path):
 
 
 def test_batch_driver_on_one_gpu(tmp_path):
-    """bo1_GoICP.py's loop through the driver: the two tsv rows whose cavity files exist, registered on this GPU."""
+    """bo1_GoICP.py's loop through the driver: the two tsv rows whose cavity files exist, registered on this GPU, and the RMSD of
+    each -- the source protein transformed with the GPU path's own rescaled R, t, against the aligned reference protein -- equal to
+    the reference's known answers 1.73675334 / 13.9296408."""
     import shutil
-    from goicp_amd import driver
+    from goicp_amd import driver, c4_batch
     data = os.path.join(GOLDEN, "data")
-    base = os.path.join(str(tmp_path), "work"); shutil.copytree(data, base)
+    base = os.path.join(str(tmp_path).replace(".", "_"), "work")
+    tsv, _, _ = c4_batch.materialise(base, data, rows=2)            # rows 1-2 = the shipped pairs incl. their protein files
     cfgp = os.path.join(base, "config.txt"); _default_config_file(cfgp)
     outd = os.path.join(base, "output")
-
-    def reg(tf, sf, nd, config, output, k):
-        return goicp_amd.run_pair_files(base, tf, sf, nd, config, output, k)
-    recs, n = driver.run_batch(base, os.path.join(base, "cavities_similar_BO1_clean.tsv"), cfgp, outd, reg)
+    reg = driver.gpu_register_fn(base)
+    recs, n = driver.run_batch(base, tsv, cfgp, outd, reg)
     # the same batch with both registrations in flight at once (one engine + stream each): same records up to the timing fields
-    recs2, _ = driver.run_batch(base, os.path.join(base, "cavities_similar_BO1_clean.tsv"), cfgp, outd, reg, threads=2)
+    recs2, _ = driver.run_batch(base, tsv, cfgp, outd, reg, threads=2)
     keep = [i for i in range(driver.REC) if i not in (16, 17)]
     assert all(np.array_equal(a[keep], b[keep], equal_nan=True) for a, b in zip(recs, recs2))
     allr = driver.gather_records(recs, n)
-    assert n == 383 and allr.shape[0] == 2
+    assert n == 2 and allr.shape[0] == 2
     G = load_register()
     assert np.float32(allr[0, 13]) == np.float32(G["pair1_default"]["error"]) and np.float32(allr[1, 13]) == np.float32(G["pair2_default"]["error"])
     assert int(allr[0, 14]) == 133 and int(allr[1, 14]) == 118
+    assert np.float32(allr[0, 19]) == np.float32(1.73675334) and np.float32(allr[1, 19]) == np.float32(13.9296408)
+    # ... and the transformed protein of pair 1 is the shipped rot/rot_2x86_3_protein.mol2, byte for byte
+    import gzip
+    want = gzip.open(os.path.join(data, "proteins", "rot_2x86_3_protein.mol2.gz"), "rb").read()
+    assert open(os.path.join(base, "rot", "rot_2x86_3_protein.mol2"), "rb").read() == want
+    # the reference's own .tsv (383 rows, 2 with files) goes through the same driver
+    shutil.copyfile(os.path.join(data, "cavities_similar_BO1_clean.tsv"), os.path.join(base, "cavities_similar_BO1_clean.tsv"))
+    recs3, n3 = driver.run_batch(base, os.path.join(base, "cavities_similar_BO1_clean.tsv"), cfgp, outd, reg)
+    assert n3 == 383 and len(recs3) == 2 and all(np.array_equal(a[keep], b[keep], equal_nan=True) for a, b in zip(recs, recs3))
+
+
+C4_ROWS = 48          # rows of the configs[3] batch run under pytest (the bench runs all 383)
+C4_ORACLE_BUDGET = 300000
+
+
+def test_c4_batch_through_the_driver_against_the_oracle(tmp_path):
+    """BASELINE configs[3]: the cavity batch under the c-FPFH weighted error (cfpfh=1, regularizationFPFH=5e-6) through
+    driver.run_batch with several registrations in flight. Every row the single-threaded oracle can finish (at most 300 k cube
+    evaluations on the GPU run) is compared with the oracle fed by the SAME files: error, compatibility count and the Error*
+    trace bit for bit, R, t to 1e-9; the rest are listed. RMSD of synthetic rows against the planted pose."""
+    from concurrent.futures import ThreadPoolExecutor
+    from goicp_amd import driver, c4_batch
+    from oracle.refbind import Oracle, read_config, read_mol2, normalise_pair, read_cfpfh, error_trace, CFG_KEYS
+    base = os.path.join(str(tmp_path).replace(".", "_"), "c4")
+    tsv, cfgp, truth = c4_batch.materialise(base, os.path.join(GOLDEN, "data"), rows=C4_ROWS)
+    outd = os.path.join(base, "output")
+    recs, n = driver.run_batch(base, tsv, cfgp, outd, driver.gpu_register_fn(base), threads=6)
+    allr = driver.gather_records(recs, n)
+    assert n == C4_ROWS and allr.shape[0] == C4_ROWS and list(allr[:, 0]) == [float(k) for k in range(1, C4_ROWS + 1)]
+    assert (allr[:, 20] == 0).all()
+    G = load_register()
+    assert np.float32(allr[0, 13]) == np.float32(G["pair1_fpfh"]["error"])          # row 1 under this config is a reference known answer
+    cfg = read_config(cfgp); v = np.array([cfg[k] for k in CFG_KEYS], np.float64)
+    jobs, _ = driver.list_jobs(base, tsv)
+
+    def check(job):
+        k, tf, sf, nd, cost, src, tgt = job
+        rec = allr[k - 1]
+        if rec[18] > C4_ORACLE_BUDGET:
+            return k, None
+        sx, sc = read_mol2(os.path.join(base, sf)); tx, tc = read_mol2(os.path.join(base, tf))
+        sn, tn = normalise_pair(sx, tx)[:2]
+        o = Oracle(); o.set_config(v)
+        o.set_clouds(tn, sn, tc, sc, read_cfpfh(os.path.join(base, "cfpfh", tgt + "_cavity6.cfpfh"), len(tn)), read_cfpfh(os.path.join(base, "cfpfh", src + "_cavity6.cfpfh"), len(sn)))
+        o.build_dt(); ro = o.register(); o.close()
+        want = open(os.path.join(outd, "similar%d.txt" % k)).read().splitlines()
+        ok = (np.float32(rec[13]) == np.float32(ro["error"]) and int(rec[14]) == int(ro["Nd"] - ro["comp"])
+              and np.abs(rec[1:10].reshape(3, 3) - ro["R"]).max() < 1e-9 and np.abs(rec[10:13] - ro["t"]).max() < 1e-9
+              and want[-2] == "Error: %g" % ro["error"])
+        return k, ok
+    with ThreadPoolExecutor(max_workers=8) as ex:
+        res = list(ex.map(check, jobs))
+    skipped = [k for k, ok in res if ok is None]; bad = [k for k, ok in res if ok is False]
+    print("configs[3] batch: %d rows, %d compared with the oracle, %d beyond its budget: %s" % (len(res), len(res) - len(skipped), len(skipped), skipped))
+    assert not bad, bad
+    assert len(res) - len(skipped) >= C4_ROWS // 2
+    # RMSD slot: filled for every row; synthetic rows whose registration found the planted pose have a small RMSD
+    assert not np.isnan(allr[:, 19]).any()
+    assert np.float32(allr[0, 19]) > 0
+    syn = allr[2:, 19]
+    assert (syn < 2.0).mean() > 0.5, syn
 
 
 @pytest.mark.parametrize("n", [25, 240, 900])
