@@ -41,7 +41,8 @@ class _Desc(C.Structure):
                 ("data_fpfh", C.c_void_p), ("weights", C.c_void_p), ("maxRotDis", C.c_void_p), ("inlierNum", C.c_int32),
                 ("doTrim", C.c_int32), ("norm", C.c_int32), ("cfpfh", C.c_int32), ("regularization", C.c_float),
                 ("regularizationNeighbors", C.c_float), ("regularizationFPFH", C.c_float), ("device_id", C.c_int32),
-                ("parity_mode", C.c_int32)]
+                ("parity_mode", C.c_int32), ("dt_dist_dev", C.c_void_p), ("nearest_occ_dev", C.c_void_p), ("n_occ", C.c_int32),
+                ("occ_cells", C.c_void_p), ("occ_color", C.c_void_p), ("occ_ptr", C.c_void_p)]
 
 
 class BnbJob(C.Structure):
@@ -212,6 +213,11 @@ class Engine:
     def stream(self):
         return self.L.goicp_engine_stream(self.h)
 
+    def search_stats(self):
+        r = C.c_uint64(); c = C.c_uint64()
+        self.L.goicp_engine_search_stats(self.h, C.byref(r), C.byref(c))
+        return dict(rounds=r.value, cube_evals_launched=c.value)
+
     def eval_kernel_name(self):
         return self.L.goicp_engine_eval_kernel_name(self.h).decode()
 
@@ -224,13 +230,20 @@ class Engine:
 class GoICP:
     """Registration-level surface (GoICP::BuildDT / Register) through include/goicp_c.h."""
 
-    def __init__(self, cfgvec=None, device_id=0, parity_mode=1, speculate=128, verbose=0):
+    def __init__(self, cfgvec=None, device_id=0, parity_mode=1, speculate=128, verbose=0, dt_mode=0):
         self.L = load_library()
         self.h = C.c_void_p(self.L.goicp_new())
         self.Nd = self.Nm = 0
         if cfgvec is not None:
             self.set_config(cfgvec)
         self.L.goicp_set_options(self.h, int(device_id), int(parity_mode), int(speculate), int(verbose))
+        if dt_mode:
+            self.set_dt_mode(dt_mode)
+
+    def set_dt_mode(self, mode):
+        """0: the reference's DT3D::Build restated on the host (bit-identical grid); 1: exact transform built on the device (opt-in)."""
+        if self.L.goicp_set_dt_mode(self.h, int(mode)) != GOICP_OK:
+            raise EngineError("set_dt_mode")
 
     def close(self):
         if self.h:
@@ -264,6 +277,8 @@ class GoICP:
 
     def build_dt(self):
         self.L.goicp_build_dt(self.h)
+        if self.L.goicp_status(self.h) != GOICP_OK:
+            raise EngineError("build_dt: %s" % self.L.goicp_error_message(self.h).decode())
         g = np.zeros(8); self.L.goicp_dt_geom(self.h, _ptr(g)); self.geom = g; self.S = int(g[7])
 
     def load_dt(self, S, geom8, dist, nearest_lin=None, cellc=None, cell_ptr=None, cell_idx=None):

@@ -63,7 +63,7 @@ struct DevTables {
     unsigned long long* dbg_times;   // [8] per-phase cycle sums of job 0, lane 0 (GOICP_DBG & 32)
 };
 
-struct HeapNode { float x, y, z, w, ub, lb; };
+struct __attribute__((aligned(8))) HeapNode { float x, y, z, w, ub, lb; };
 
 // ---------------------------------------------------------------------------------------------
 // device helpers
@@ -842,19 +842,66 @@ __device__ __forceinline__ void lattice_fpfh_oct(const DevTables& T, TileShm<BLO
 // ---------------------------------------------------------------------------------------------
 __device__ __forceinline__ bool node_lower(const HeapNode& p, const HeapNode& q) { return p.lb != q.lb ? p.lb > q.lb : p.w < q.w; }
 
+// node of the round-based search (k_fr_*): the queue entry plus the slot that holds its children's bounds once they are known
+struct __attribute__((aligned(16))) HeapNodeX { float x, y, z, w, ub, lb; int exp; int pad; };
+
 // storage: the first `hl` nodes live in LDS (the hot top of the heap), the rest in the job's global slab
-struct HeapStore {
-    HeapNode* lds; HeapNode* glb; int hl;
-    __device__ __forceinline__ HeapNode get(int i) const { return i < hl ? lds[i] : glb[i]; }
-    __device__ __forceinline__ void set(int i, const HeapNode& v) const { if (i < hl) lds[i] = v; else glb[i] = v; }
+// Node moves go through explicit LDS / global address spaces: a plain `i < hl ? lds[i] : glb[i]` makes the compiler merge the two
+// pointers into a generic one and emit flat_load / flat_store, whose latency (and the double s_waitcnt they need) dominated the queue
+// work (k_fr_select: 10.8 k cycles per pop before, see profiles/).
+typedef unsigned qv4 __attribute__((ext_vector_type(4)));
+typedef unsigned qv2 __attribute__((ext_vector_type(2)));
+template <class N> struct NodeWords { typedef qv2 V; };
+template <> struct NodeWords<HeapNodeX> { typedef qv4 V; };
+template <class N>
+struct HeapStoreT {
+    N* lds; N* glb; int hl;
+    typedef typename NodeWords<N>::V V;
+    static constexpr int NV = sizeof(N) / sizeof(V);
+    union Pun { N n; V v[NV]; __device__ Pun() {} };
+    __device__ __forceinline__ N get(int i) const {
+        Pun u;
+        if (i < hl) {
+            const __attribute__((address_space(3))) V* q = (const __attribute__((address_space(3))) V*)(lds + i);
+#pragma unroll
+            for (int k = 0; k < NV; k++) u.v[k] = q[k];
+        } else {
+            const __attribute__((address_space(1))) V* q = (const __attribute__((address_space(1))) V*)(glb + i);
+#pragma unroll
+            for (int k = 0; k < NV; k++) u.v[k] = q[k];
+        }
+        return u.n;
+    }
+    __device__ __forceinline__ void set(int i, const N& v) const {
+        Pun u; u.n = v;
+        if (i < hl) {
+            __attribute__((address_space(3))) V* q = (__attribute__((address_space(3))) V*)(lds + i);
+#pragma unroll
+            for (int k = 0; k < NV; k++) q[k] = u.v[k];
+        } else {
+            __attribute__((address_space(1))) V* q = (__attribute__((address_space(1))) V*)(glb + i);
+#pragma unroll
+            for (int k = 0; k < NV; k++) q[k] = u.v[k];
+        }
+    }
 };
+typedef HeapStoreT<HeapNode> HeapStore;
 __device__ __forceinline__ bool key_lower(float plb, float pw, float qlb, float qw) { return plb != qlb ? plb > qlb : pw < qw; }
 struct HeapKey { float lb, w; };
-__device__ __forceinline__ HeapKey heap_key(const HeapStore& a, int i) {
-    const HeapNode* p = i < a.hl ? a.lds + i : a.glb + i;
-    HeapKey k; k.lb = p->lb; k.w = p->w; return k;
+template <class N>
+__device__ __forceinline__ HeapKey heap_key(const HeapStoreT<N>& a, int i) {
+    HeapKey k;
+    if (i < a.hl) {
+        const __attribute__((address_space(3))) float* q = (const __attribute__((address_space(3))) float*)(a.lds + i);
+        k.w = q[3]; k.lb = q[5];
+    } else {
+        const __attribute__((address_space(1))) float* q = (const __attribute__((address_space(1))) float*)(a.glb + i);
+        k.w = q[3]; k.lb = q[5];
+    }
+    return k;
 }
-__device__ __forceinline__ void heap_up(const HeapStore& a, int hole, const HeapNode& v) {
+template <class N>
+__device__ __forceinline__ void heap_up(const HeapStoreT<N>& a, int hole, const N& v) {
     int par = (hole - 1) / 2;
     while (hole > 0) {
         const HeapKey pk = heap_key(a, par);                      // compare on (lb, w) only; move whole nodes only when needed
@@ -867,10 +914,11 @@ __device__ __forceinline__ void heap_up(const HeapStore& a, int hole, const Heap
 // one ballot tells how many of them v passes (the leading run of "ancestor is lower"), those ancestors drop one slot down
 // the path in parallel and v lands above them -- the arrangement std::push_heap's loop produces, in one round trip to
 // the queue instead of one per level.
-__device__ __forceinline__ void heap_up_wave(const HeapStore& a, int hole, const HeapNode& v, int lane) {
+template <class N>
+__device__ __forceinline__ void heap_up_wave(const HeapStoreT<N>& a, int hole, const N& v, int lane) {
     const int depth = 31 - __clz(hole + 1);                      // ancestors: ((hole+1) >> (k+1)) - 1, k = 0 .. depth-1
     const bool act = lane < depth;
-    HeapNode nk = v; bool rises = false;
+    N nk = v; bool rises = false;
     if (act) { nk = a.get(((hole + 1) >> (lane + 1)) - 1); rises = key_lower(nk.lb, nk.w, v.lb, v.w); }
     const unsigned long long up = __ballot(rises);
     const int m = min(depth, __ffsll((long long)~up) - 1);       // lanes >= depth never rise, so ~up is never 0
@@ -879,10 +927,11 @@ __device__ __forceinline__ void heap_up_wave(const HeapStore& a, int hole, const
     if (lane == 0) a.set(((hole + 1) >> m) - 1, v);
     wave_sync_lds();
 }
-__device__ __forceinline__ void heap_pop(const HeapStore& a, int& n) {
+template <class N>
+__device__ __forceinline__ void heap_pop(const HeapStoreT<N>& a, int& n) {
     if (n > 1) {
         const int len = n - 1;
-        const HeapNode v = a.get(len);
+        const N v = a.get(len);
         a.set(len, a.get(0));
         int hole = 0, child = 0;
         while (child < (len - 1) / 2) {
@@ -897,6 +946,37 @@ __device__ __forceinline__ void heap_pop(const HeapStore& a, int& n) {
     n--;
 }
 
+// heap_pop for a whole wave (uniform n): every lane walks the same path with broadcast reads, both children of a level are
+// fetched whole in one round trip (the chosen one moves up without a second read), lane 0 does the stores, and the displaced
+// last element rises with heap_up_wave. Same arrangement as heap_pop / std::pop_heap.
+template <class N>
+__device__ __forceinline__ void heap_pop_wave(const HeapStoreT<N>& a, int& n, int lane) {
+    if (n > 1) {
+        const int len = n - 1;
+        const N v = a.get(len);
+        const N top = a.get(0);
+        if (lane == 0) a.set(len, top);
+        int hole = 0, child = 0;
+        while (child < (len - 1) / 2) {
+            child = 2 * (child + 1);
+            const N c1 = a.get(child), c0 = a.get(child - 1);
+            const bool left = key_lower(c1.lb, c1.w, c0.lb, c0.w);
+            if (left) child--;
+            if (lane == 0) a.set(hole, left ? c0 : c1);
+            hole = child;
+        }
+        if ((len & 1) == 0 && child == (len - 2) / 2) {
+            child = 2 * (child + 1);
+            const N c0 = a.get(child - 1);
+            if (lane == 0) a.set(hole, c0);
+            hole = child - 1;
+        }
+        wave_sync_lds();
+        heap_up_wave(a, hole, v, lane);
+    }
+    n--;
+}
+
 // ---------------------------------------------------------------------------------------------
 // sweep_stream: the tile sweep for clouds that do not fit a workgroup's registers (Nd > 8192; geometric error only, fp64 sums).
 // The workgroup walks the rotated cloud in chunks of 1024 points (coalesced float4 reads), 8 gathers per lane and chunk.
@@ -905,14 +985,16 @@ __device__ __forceinline__ void heap_pop(const HeapStore& a, int& n) {
 // sweep_tile: one pass over the rows for the 1024-bin window, one pass that sums everything below the threshold bin and
 // collects the bin's members, in-wave bisection of the low 16 bits; the generic byte passes re-read the rows.
 // ---------------------------------------------------------------------------------------------
-template <bool OCT, int BLOCK = 1024>
+// PARTIAL = true (untrimmed runs only): the workgroup sweeps the points [p0, p1) of the cloud and leaves its 16 fp64 partial sums
+// (ub, lb per cube) in part_out instead of finishing the bounds -- one node's sweep split over several workgroups (k_fr_expand).
+template <bool OCT, int BLOCK = 1024, bool PARTIAL = false>
 __device__ __forceinline__ void sweep_stream(const DevTables& T, TileShm<BLOCK>& sh, const float4* __restrict__ rot, const float* __restrict__ rho_row,
-                                             float* __restrict__ rows, int NdP) {
+                                             float* __restrict__ rows, int NdP, int p0 = 0, int p1 = 0, double* __restrict__ part_out = nullptr) {
     const int tid = threadIdx.x, wv = tid >> 6, ln = tid & 63;
-    const int Nd = T.Nd, S = T.S;
+    const int Nd = PARTIAL ? p1 : T.Nd, S = T.S;
     const bool row_mode = !OCT && sh.ctl[2];
     const bool sq = T.norm == 2, lin = T.norm == 1;
-    const bool trim = T.doTrim != 0;
+    const bool trim = !PARTIAL && T.doTrim != 0;
     double su[TC], sl[TC]; unsigned mx[TC];
 #pragma unroll
     for (int j = 0; j < TC; j++) { su[j] = 0.0; sl[j] = 0.0; mx[j] = 0u; }
@@ -924,9 +1006,10 @@ __device__ __forceinline__ void sweep_stream(const DevTables& T, TileShm<BLOCK>&
         if (e > 0.f) sl[j] += (double)tl;
     };
     // the next chunk's point is fetched while the current chunk's gathers are in flight
-    float4 pnext = rot[min(tid, Nd - 1)];
-    float rnext = rho_row ? rho_row[min(tid, Nd - 1)] : 0.f;
-    for (int b = 0; b < Nd; b += BLOCK) {
+    const int pbeg = PARTIAL ? p0 : 0;
+    float4 pnext = rot[min(pbeg + tid, Nd - 1)];
+    float rnext = rho_row ? rho_row[min(pbeg + tid, Nd - 1)] : 0.f;
+    for (int b = pbeg; b < Nd; b += BLOCK) {
         const int i = b + tid;
         const bool valid = i < Nd;
         const float4 p = pnext;
@@ -1170,14 +1253,17 @@ __device__ __forceinline__ void sweep_stream(const DevTables& T, TileShm<BLOCK>&
         if (tid == j) {
             double u = 0.0, l = 0.0;
             for (int w = 0; w < BLOCK / 64; w++) { u += sh.red[w][2 * j]; l += sh.red[w][2 * j + 1]; }
-            if (trim) {
-                const float d = __uint_as_float(thr[j]);
-                const float e = d - sh.mtd[j];
-                const double n = (double)(T.inlierNum - below[j]);
-                if (sq) { u += n * (double)(d * d); if (e > 0.f) l += n * (double)(e * e); }
-                else if (lin) { u += n * (double)d; if (e > 0.f) l += n * (double)e; }
+            if (PARTIAL) { part_out[2 * j] = u; part_out[2 * j + 1] = l; }
+            else {
+                if (trim) {
+                    const float d = __uint_as_float(thr[j]);
+                    const float e = d - sh.mtd[j];
+                    const double n = (double)(T.inlierNum - below[j]);
+                    if (sq) { u += n * (double)(d * d); if (e > 0.f) l += n * (double)(e * e); }
+                    else if (lin) { u += n * (double)d; if (e > 0.f) l += n * (double)e; }
+                }
+                sh.ub[j] = (float)u; sh.lb[j] = (float)l;
             }
-            sh.ub[j] = (float)u; sh.lb[j] = (float)l;
         }
     }
     __syncthreads();
@@ -1198,7 +1284,7 @@ __global__ __launch_bounds__(BLOCK, (BLOCK == 256 ? 2 : (JIT ? 4 : 1))) void k_i
                                                       HeapNode* heaps, int heap_cap, float* fpscratch, unsigned max_pops, int heap_lds_nodes, int rbuf_floats, int fp_lds) {
     __shared__ TileShm<BLOCK> sh;
     __shared__ HeapNode parent;
-    extern __shared__ float rbuf[];              // [rbuf_floats] parity-mode residual rows, then the LDS part of the heap
+    extern __shared__ __attribute__((aligned(16))) float rbuf[];   // [rbuf_floats] parity-mode residual rows, then the LDS part of the heap
     const int tid = threadIdx.x;
     const int Nd = T.Nd;
     const goicp_bnb_job job = jobs[blockIdx.x];
@@ -1349,6 +1435,287 @@ __global__ __launch_bounds__(BLOCK, (BLOCK == 256 ? 2 : (JIT ? 4 : 1))) void k_i
         r.optErrorT = optErrorT; r.node[0] = bx; r.node[1] = by; r.node[2] = bz; r.node[3] = bw;
         r.found = found; r.status = status; r.pops = pops; r.cube_evals = cubes;
         results[blockIdx.x] = r;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Round-based InnerBnB for large clouds (k_fr_init / k_fr_select / k_fr_expand): one search uses MANY workgroups.
+//
+// k_inner_bnb gives a search one workgroup; above cavity size a queue pop then costs tens of microseconds (8 x Nd gathers + the
+// inlier selection on one CU) and a registration waits for its longest chain of pops while most of the chip idles. The bounds of a
+// cube are pure functions of (rotation, level, cube) (reference jly_goicp.cpp:325-415), so the children of SEVERAL queue nodes can
+// be evaluated at once and the reference's pop / prune / push sequence replayed afterwards from the stored values:
+//   k_fr_select  one wave per search. Replays jly_goicp.cpp:303-575 on the search's queue for as long as the node on top already has
+//                its children's bounds (same heap arrangement, same tie order, same stop test as k_inner_bnb), then marks up to K
+//                nodes near the top of the queue that lack them and appends them to the launch-wide work list.
+//   k_fr_expand  persistent workgroups drain the work list: one item = the 8 children of one node (one sweep tile over the search's
+//                rotated cloud), or, for streamed untrimmed clouds, one slice of the points of such a tile (fp64 partial sums that the
+//                next k_fr_select adds up in slice order).
+// Rounds are separated by kernel boundaries (no in-kernel cross-workgroup hand-off); the host enqueues batches of rounds and looks
+// at the count of unfinished searches between batches. Results are those of the sequential search: speculation only decides WHEN
+// a node's children are evaluated, never which nodes the replay pops.
+// ---------------------------------------------------------------------------------------------
+struct __attribute__((aligned(16))) FrExp { float ub[TC], lb[TC]; int child_base; int pad[3]; };   // child_base: first of the 8 records of the children's own children, or -1
+struct FrItem { int job, eid, split, pad; float x, y, z, w; };
+struct FrState {
+    float optErrorT, bx, by, bz, bw;
+    int found, status, done;
+    unsigned pops, cubes, spec;
+    int hn, ne, pend0, pad0, pad1;
+};
+struct FrCtx {
+    const goicp_bnb_job* jobs; FrState* st; goicp_bnb_result* results;
+    HeapNodeX* heaps; int heap_cap;
+    FrExp* exps; int exp_cap;
+    FrItem* wl; int wl_cap; unsigned* wl_count;      // wl_count[round], zeroed per batch of rounds
+    unsigned* active;                                  // active[round] = searches still running after that round's select
+    double* parts; int nsplit;                         // [job][eid][split][16] partial sums (streamed untrimmed clouds), else null / 1
+    int ngroups;                                       // work items per node and point slice: 1 (all 8 children) or 2 (4 children each)
+    float4* srot; int NdP;                             // rotated clouds [job][NdP]
+    unsigned max_pops;
+    unsigned long long* dbg;                           // [8] cycle sums of the busiest-looking phases of k_fr_select (GOICP_DBG & 32), else null
+};
+#define FR_LDS_NODES 4095          // queue nodes staged in LDS by k_fr_select (32 B each: 128 KB)
+#define FR_SELECT_THREADS 256
+
+__global__ __launch_bounds__(256) void k_fr_init(DevTables T, FrCtx C) {
+    const int job = blockIdx.x, tid = threadIdx.x;
+    const goicp_bnb_job jb = C.jobs[job];
+    float4* srot = C.srot + (size_t)job * C.NdP;
+    for (int i = tid; i < T.Nd; i += 256) {            // K5: pDataTemp = R*p, float, left to right (reference jly_goicp.cpp:750-756)
+        const float x = T.dxyz[3 * i], y = T.dxyz[3 * i + 1], z = T.dxyz[3 * i + 2];
+        float4 p;
+        p.x = jb.R[0] * x + jb.R[1] * y + jb.R[2] * z;
+        p.y = jb.R[3] * x + jb.R[4] * y + jb.R[5] * z;
+        p.z = jb.R[6] * x + jb.R[7] * y + jb.R[8] * z;
+        p.w = T.weights[i];
+        srot[i] = p;
+    }
+    if (tid == 0) {
+        HeapNodeX root; root.x = jb.init[0]; root.y = jb.init[1]; root.z = jb.init[2]; root.w = jb.init[3]; root.ub = 0.f; root.lb = jb.init_lb; root.exp = -1; root.pad = 0;
+        C.heaps[(size_t)job * C.heap_cap] = root;
+        FrState st; st.optErrorT = jb.optError_in; st.bx = st.by = st.bz = st.bw = 0.f; st.found = 0; st.status = GOICP_OK; st.done = 0;
+        st.pops = st.cubes = st.spec = 0u; st.hn = 1; st.ne = 0; st.pend0 = 0; st.pad0 = st.pad1 = 0;
+        C.st[job] = st;
+    }
+}
+
+__global__ __launch_bounds__(FR_SELECT_THREADS) void k_fr_select(FrCtx C, int round, int K, int depth) {
+    __shared__ HeapNodeX top[FR_LDS_NODES];
+    __shared__ FrExp ecache[64];
+    __shared__ int s_hi;
+    const int job = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
+    const bool w0 = tid < 64;                       // wave 0 replays and selects; the other waves only move the queue in and out of LDS
+    FrState st = C.st[job];
+    if (st.done) return;
+    const bool timing = C.dbg != nullptr && w0;
+    unsigned long long tph[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tlast = timing ? clock64() : 0ull;
+    const unsigned long long wall0 = timing ? wall_clock64() : 0ull;
+#define FSTAMP(k) do { if (timing) { const unsigned long long now_ = clock64(); tph[k] += now_ - tlast; tlast = now_; } } while (0)
+    const goicp_bnb_job jb = C.jobs[job];
+    HeapNodeX* hg = C.heaps + (size_t)job * C.heap_cap;
+    FrExp* ex = C.exps + (size_t)job * C.exp_cap;
+    // children's bounds of the nodes expanded in the previous round whose sweeps were split over several workgroups: add the slices up
+    if (C.parts) {
+        for (int e = st.pend0 + (tid >> 4); e < st.ne; e += FR_SELECT_THREADS / 16) {
+            const int k = tid & 15;
+            const double* pp = C.parts + ((size_t)job * C.exp_cap + e) * C.nsplit * 16 + k;
+            double acc = 0.0;
+            for (int q = 0; q < C.nsplit; q++) acc += pp[(size_t)q * 16];
+            if (k & 1) ex[e].lb[k >> 1] = (float)acc; else ex[e].ub[k >> 1] = (float)acc;
+        }
+        __threadfence_block();
+    }
+    st.pend0 = st.ne;
+    // the queue (its first FR_LDS_NODES nodes) is staged in LDS for the replay and written back afterwards, by all waves
+    const int nl = min(st.hn, FR_LDS_NODES);
+    {
+        const qv4* src = reinterpret_cast<const qv4*>(hg); qv4* dst = reinterpret_cast<qv4*>(top);
+        for (int i = tid; i < 2 * nl; i += FR_SELECT_THREADS) dst[i] = src[i];
+    }
+    __syncthreads();
+    HeapStoreT<HeapNodeX> heap; heap.lds = top; heap.glb = hg; heap.hl = FR_LDS_NODES;
+    int hn = st.hn, hi_water = nl;
+    if (w0) {
+    // the children's bounds of the nodes near the top of the queue are fetched now, all at once (one lane each), instead of one
+    // dependent global read per replayed pop; pops of nodes that sat deeper fall back to the global read
+    int my_eid = -1;
+    if (lane < 63 && lane < hn) my_eid = top[lane].exp;
+    if (my_eid >= 0) ecache[lane] = ex[my_eid];
+    wave_sync_lds();
+    FSTAMP(0);
+    const unsigned pop_limit = jb.max_pops ? jb.max_pops : C.max_pops;
+    for (;;) {
+        if (hn == 0) { st.done = 1; break; }
+        const HeapNodeX par = heap.get(0);
+        // (the search ends on these three: the queue is not used again, so the pop itself is only counted)
+        if (st.optErrorT - par.lb < jb.SSEThresh) { st.pops++; st.done = 1; break; }                                   // reference jly_goicp.cpp:317
+        if (st.pops + 1 > pop_limit) { st.pops++; st.done = 1; st.status = GOICP_ERR_LIMIT; break; }
+        if (hn - 1 + 8 > C.heap_cap || (par.exp < 0 && st.ne + 9 > C.exp_cap)) { st.pops++; st.done = 1; st.status = GOICP_ERR_OVERFLOW; break; }
+        if (par.exp < 0) break;                                         // its children have not been evaluated yet
+        FSTAMP(1);
+        heap_pop_wave(heap, hn, lane);
+        FSTAMP(2);
+        st.pops++; st.cubes += 8;
+        const unsigned long long hit = __ballot(my_eid == par.exp);
+        FrExp E;
+        {   // explicit address spaces (a pointer select would turn these into flat loads)
+            qv4* ev = reinterpret_cast<qv4*>(&E);
+            if (hit) {
+                const __attribute__((address_space(3))) qv4* q = (const __attribute__((address_space(3))) qv4*)(ecache + (__ffsll((long long)hit) - 1));
+#pragma unroll
+                for (int k = 0; k < (int)(sizeof(FrExp) / 16); k++) ev[k] = q[k];
+            } else {
+                const __attribute__((address_space(1))) qv4* q = (const __attribute__((address_space(1))) qv4*)(ex + par.exp);
+#pragma unroll
+                for (int k = 0; k < (int)(sizeof(FrExp) / 16); k++) ev[k] = q[k];
+            }
+        }
+        if (timing) { tph[6] += 1; if (!hit) tph[7] += 1; }
+        const float w = par.w / 2;
+#pragma unroll
+        for (int j = 0; j < TC; j++) {                                  // incumbent update, prune, push (reference jly_goicp.cpp:554-575)
+            const float ub = E.ub[j], lb = E.lb[j];
+            const float cx = par.x + (j & 1) * w, cy = par.y + (j >> 1 & 1) * w, cz = par.z + (j >> 2 & 1) * w;
+            if (ub < st.optErrorT) { st.optErrorT = ub; st.bx = cx; st.by = cy; st.bz = cz; st.bw = w; st.found = 1; }
+            if (lb >= st.optErrorT) continue;
+            HeapNodeX nd; nd.x = cx; nd.y = cy; nd.z = cz; nd.w = w; nd.ub = ub; nd.lb = lb; nd.pad = 0;
+            nd.exp = E.child_base >= 0 ? E.child_base + j : -1;        // this child's own children were evaluated together with it
+            hn++;
+            heap_up_wave(heap, hn - 1, nd, lane);
+        }
+        hi_water = max(hi_water, min(hn, FR_LDS_NODES));
+        FSTAMP(3);
+    }
+    wave_sync_lds();
+    FSTAMP(1);
+    // nodes to expand next: the (up to K) best keys without children's bounds among the first 63 queue slots (the true head of
+    // the queue is always among them; deeper slots are picked up in later rounds). depth 2: the 8 children of a chosen node are
+    // expanded in the same round (9 tiles per node), so a search that keeps diving into fresh children needs half the rounds.
+    if (!st.done) {
+        const bool have = lane < 63 && lane < hn;
+        HeapNodeX me; me.lb = 0.f; me.w = 0.f; me.exp = 0; me.x = me.y = me.z = me.ub = 0.f; me.pad = 0;
+        if (have) me = heap.get(lane);
+        // a node whose bound already meets the stop test can never be expanded (the incumbent only falls): not worth a sweep
+        const bool want = have && me.exp < 0 && !(st.optErrorT - me.lb < jb.SSEThresh);
+        int rank = 0;
+        for (int m = 0; m < 63; m++) {
+            const float olb = __shfl(me.lb, m, 64), ow = __shfl(me.w, m, 64);
+            const int owant = __shfl((int)want, m, 64);
+            const bool better = olb != me.lb ? olb < me.lb : (ow != me.w ? ow > me.w : m < lane);
+            rank += (owant && better) ? 1 : 0;
+        }
+        const int slots = depth >= 2 ? 9 : 1;                          // expansion records per chosen node
+        const bool sel = want && rank < K && st.ne + (rank + 1) * slots <= C.exp_cap;
+        const int nsel = __popcll(__ballot(sel));
+        if (nsel) {
+            // (ranks of the selected lanes are 0 .. nsel-1: a selected lane's betters are all selected too)
+            unsigned base = 0;
+            const int per_tile = C.nsplit * C.ngroups, per_node = per_tile * slots;
+            if (lane == 0) base = atomicAdd(&C.wl_count[round], (unsigned)(nsel * per_node));
+            base = (unsigned)__shfl((int)base, 0, 64);
+            if (sel) {
+                const int eid = st.ne + rank * slots;
+                const unsigned at = base + (unsigned)(rank * per_node);
+                if (at + per_node <= (unsigned)C.wl_cap) {
+                    const float hw = me.w / 2;
+                    for (int t = 0; t < slots; t++) {
+                        FrItem it; it.job = job; it.eid = eid + t; it.pad = slots == 9 && t == 0 ? eid + 1 : -1;    // pad = child_base of the record
+                        if (t == 0) { it.x = me.x; it.y = me.y; it.z = me.z; it.w = me.w; }
+                        else { const int j = t - 1; it.x = me.x + (j & 1) * hw; it.y = me.y + (j >> 1 & 1) * hw; it.z = me.z + (j >> 2 & 1) * hw; it.w = hw; }
+                        for (int q = 0; q < per_tile; q++) { it.split = q; C.wl[at + t * per_tile + q] = it; }
+                    }
+                    me.exp = eid;
+                    heap.set(lane, me);
+                }
+            }
+            st.ne += nsel * slots; st.spec += 8u * nsel * slots;
+        }
+    }
+    wave_sync_lds();
+    FSTAMP(4);
+    if (lane == 0) s_hi = hi_water;
+    }
+    __syncthreads();
+    {
+        const int hw2 = 2 * s_hi;
+        const qv4* src = reinterpret_cast<const qv4*>(top); qv4* dst = reinterpret_cast<qv4*>(hg);
+        for (int i = tid; i < hw2; i += FR_SELECT_THREADS) dst[i] = src[i];
+    }
+    FSTAMP(5);
+    if (timing && lane == 0) {
+        // per phase: summed over all searches and rounds (atomic adds); [6] replayed pops, [7] of which missed the prefetch
+        for (int k = 0; k < 8; k++) if (tph[k]) atomicAdd(&C.dbg[k], tph[k]);
+        atomicAdd(&C.dbg[8], wall_clock64() - wall0);
+    }
+#undef FSTAMP
+    if (tid == 0) {
+        st.hn = hn;
+        C.st[job] = st;
+        if (st.done) {
+            goicp_bnb_result r;
+            r.optErrorT = st.optErrorT; r.node[0] = st.bx; r.node[1] = st.by; r.node[2] = st.bz; r.node[3] = st.bw;
+            r.found = st.found; r.status = st.status; r.pops = st.pops; r.cube_evals = st.cubes;
+            C.results[job] = r;
+        } else atomicAdd(&C.active[round], 1u);
+    }
+}
+
+// MODE 0: register-resident residuals, points fetched just in time (sweep_tile, BLOCK 512 x PPT points per lane, Nd <= 5120); an item is
+//         NT = 8 / ngroups children of the node (two items of 4 children each keep the residuals within 128 registers at 2 workgroups per CU)
+// MODE 1: streamed cloud (sweep_stream, trimmed or untrimmed)          MODE 2: streamed untrimmed cloud, one slice of the points per item
+template <int BLOCK, int PPT, int MODE, int NT>
+__device__ __forceinline__ void fr_expand_item(const DevTables& T, const FrCtx& C, TileShm<BLOCK>& sh, const FrItem item, float* rows) {
+    const int tid = threadIdx.x;
+    const int level = C.jobs[item.job].rot_level;
+    const float4* rot = C.srot + (size_t)item.job * C.NdP;
+    const float* rho = level >= 0 ? T.maxRotDis + (size_t)level * T.Nd : nullptr;
+    const int j0 = MODE == 0 ? item.split * NT : 0;        // first child of this item
+    if (tid < TC) {                                     // children of the node (reference jly_goicp.cpp:322-333)
+        const int j = (tid < NT ? tid : 0) + j0;        // rows past NT repeat child j0 (sweep_tile reads the centre of row 4 for the second z value)
+        const float w = item.w / 2;
+        const float x = item.x + (j & 1) * w, y = item.y + (j >> 1 & 1) * w, z = item.z + (j >> 2 & 1) * w;
+        sh.cube[tid][0] = x; sh.cube[tid][1] = y; sh.cube[tid][2] = z; sh.cube[tid][3] = w;
+        sh.cen[tid][0] = x + w / 2; sh.cen[tid][1] = y + w / 2; sh.cen[tid][2] = z + w / 2;
+        sh.mtd[tid] = (float)(SQRT3_D / 2.0 * w);
+    }
+    __syncthreads();
+    FrExp* out = C.exps + (size_t)item.job * C.exp_cap + item.eid;
+    if constexpr (MODE == 0) {
+        float px[PPT], py[PPT], pz[PPT], pw[PPT], prho[PPT];
+#pragma unroll
+        for (int m = 0; m < PPT; m++) { px[m] = py[m] = pz[m] = pw[m] = prho[m] = 0.f; }
+        sweep_tile<BLOCK, PPT, true, NT, true>(T, sh, px, py, pz, pw, prho, level >= 0, nullptr, false, rot, rho);
+        if (tid < NT) { out->ub[j0 + tid] = sh.ub[tid]; out->lb[j0 + tid] = sh.lb[tid]; }
+        if (tid == 0 && item.split == 0) out->child_base = item.pad;
+    } else if constexpr (MODE == 1) {
+        sweep_stream<true, BLOCK>(T, sh, rot, rho, rows, T.NdP);
+        if (tid < TC) { out->ub[tid] = sh.ub[tid]; out->lb[tid] = sh.lb[tid]; }
+        if (tid == 0) out->child_base = item.pad;
+    } else {
+        const int per = ((T.Nd + C.nsplit - 1) / C.nsplit + 63) & ~63;
+        const int p0 = min(item.split * per, T.Nd), p1 = min(p0 + per, T.Nd);
+        double* part = C.parts + (((size_t)item.job * C.exp_cap + item.eid) * C.nsplit + item.split) * 16;
+        sweep_stream<true, BLOCK, true>(T, sh, rot, rho, nullptr, T.NdP, p0, p1, part);
+        if (tid == 0 && item.split == 0) out->child_base = item.pad;
+    }
+}
+
+template <int BLOCK, int PPT, int MODE, int NT>
+__global__ __launch_bounds__(BLOCK, (MODE == 0 ? 4 : (BLOCK == 512 ? 4 : 1))) void k_fr_expand(DevTables T, FrCtx C, int round) {
+    __shared__ TileShm<BLOCK> sh;
+    const unsigned n = min(C.wl_count[round], (unsigned)C.wl_cap);
+    if constexpr (MODE == 1) {
+        // a residual-row scratch per resident workgroup: persistent workgroups walk the list
+        float* rows = T.srows ? T.srows + (size_t)blockIdx.x * TC * T.NdP : nullptr;
+        for (unsigned it = blockIdx.x; it < n; it += gridDim.x) {
+            fr_expand_item<BLOCK, PPT, MODE, NT>(T, C, sh, C.wl[it], rows);
+            __syncthreads();
+        }
+    } else {
+        // one item per workgroup (the host sizes the grid from the number of live searches). Inside a loop the compiler hoists the
+        // per-lane point addresses of all PPT fetches out of it and the residuals no longer fit the 128 registers of 2 workgroups per CU.
+        if (blockIdx.x < n) fr_expand_item<BLOCK, PPT, MODE, NT>(T, C, sh, C.wl[blockIdx.x], nullptr);
     }
 }
 
@@ -1582,6 +1949,12 @@ struct goicp_engine {
     int resident_jobs;                       // search workgroups resident at once (CUs x occupancy of the chosen k_inner_bnb)
     int streamed; size_t stream_wgs, stream_rot_wgs;   // streaming path: scratch sized for this many resident workgroups (rows / rotated clouds)
     int jit_bnb;                             // geometric searches of 1025..2048 points: k_inner_bnb<512, 4, false, false, true>
+    // round-based search (k_fr_*): geometric searches of more than 1024 points
+    int fr_mode;                             // 0 off, else 1 + MODE of k_fr_expand
+    int fr_ppt, fr_block, fr_nsplit, fr_wgs, fr_heap_cap, fr_depth2;
+    FrState* fr_st; HeapNodeX* fr_heaps; FrExp* fr_exps; FrItem* fr_wl; unsigned* fr_cnt; double* fr_parts; float4* fr_srot; goicp_bnb_result* fr_results;
+    size_t fr_jobs, fr_cap_nodes, fr_cap_exps; int fr_wl_cap;
+    uint64_t fr_rounds, fr_spec_cubes;
     unsigned max_pops;
     uint64_t n_cubes, n_lookups; double kernel_ms;
     std::string err, kernel_name;
@@ -1711,6 +2084,7 @@ extern "C" void goicp_engine_destroy(goicp_engine* h) {
     if (h->T.srot) cache_free(h->T.srot);
     if (h->T.srows) cache_free(h->T.srows);
     if (h->d_fpscratch) cache_free(h->d_fpscratch);
+    { void* fr[] = {h->fr_st, h->fr_heaps, h->fr_exps, h->fr_wl, h->fr_cnt, h->fr_parts, h->fr_srot, h->fr_results}; for (void* p : fr) if (p) cache_free(p); }
     cache_queue_return(h->device, h->stream, h->ev0, h->ev1, h->pinned);   // (already synchronised above)
     delete h;
 }
@@ -1766,14 +2140,16 @@ extern "C" int goicp_engine_create(const goicp_engine_desc* d, goicp_engine** ou
     *out = nullptr;
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || d->device_id < 0 || d->device_id >= ndev) return GOICP_ERR_NO_DEVICE;
-    if (d->S <= 0 || !d->dt_dist || d->Nd <= 0 || !d->data_xyz || !d->weights || !d->maxRotDis || d->Nm < 0) return GOICP_ERR_ARG;
+    if (d->S <= 0 || (!d->dt_dist && !d->dt_dist_dev) || d->Nd <= 0 || !d->data_xyz || !d->weights || !d->maxRotDis || d->Nm < 0) return GOICP_ERR_ARG;
     if (d->regularizationNeighbors > 0.f) return GOICP_ERR_ARG;
     if (d->Nd > (1 << 20)) return GOICP_ERR_ARG;  // up to 8192 points the cloud is register-resident; above that it is streamed (geometric error only)
     if (d->doTrim && (d->inlierNum < 1 || d->inlierNum > d->Nd)) return GOICP_ERR_ARG;
     const bool use_compat = d->regularization > 0.f;
     const bool use_fpfh = d->regularizationFPFH > 0.f;        // entered for any cfpfh once regularizationFPFH>0 (jly_goicp.cpp:460)
     if (d->Nd > 8192 && (use_compat || use_fpfh)) return GOICP_ERR_ARG;   // streamed clouds: geometric error only (the reference's own penalty constant overflows int above 46 340 points)
-    const bool have_tables = d->nearest_occ && d->cell_color && d->cell_ptr && d->cell_idx && d->model_color && d->data_color;
+    const bool sparse = d->dt_dist_dev != nullptr;             // device-resident grid + sparse cell tables (goicp_dtgpu_build)
+    const bool have_tables = d->cell_idx && d->model_color && d->data_color &&
+                             (sparse ? (d->nearest_occ_dev && d->n_occ > 0 && d->occ_cells && d->occ_color && d->occ_ptr) : (d->nearest_occ && d->cell_color && d->cell_ptr));
     if ((use_compat || use_fpfh) && !have_tables) return GOICP_ERR_ARG;
     if (use_fpfh && (!d->model_fpfh || !d->data_fpfh)) return GOICP_ERR_ARG;
 
@@ -1783,6 +2159,8 @@ extern "C" int goicp_engine_create(const goicp_engine_desc* d, goicp_engine** ou
     h->streamed = 0; h->stream_wgs = 0; h->stream_rot_wgs = 0; h->pinned = nullptr;
     h->d_heaps = nullptr; h->d_fpscratch = nullptr; h->heap_cap = 8192; h->heap_jobs = 0; h->fp_blocks = 0; h->d_heap_big = nullptr; h->heap_big_cap = 0;
     h->n_cubes = h->n_lookups = 0; h->kernel_ms = 0; h->max_pops = 200000000u;
+    h->fr_mode = 0; h->fr_st = nullptr; h->fr_heaps = nullptr; h->fr_exps = nullptr; h->fr_wl = nullptr; h->fr_cnt = nullptr; h->fr_parts = nullptr; h->fr_srot = nullptr; h->fr_results = nullptr;
+    h->fr_jobs = 0; h->fr_cap_nodes = 0; h->fr_cap_exps = 0; h->fr_wl_cap = 0; h->fr_rounds = 0; h->fr_spec_cubes = 0;
 #define CR(call) do { int rc_ = (call); if (rc_ != GOICP_OK) { std::string m = h->err; goicp_engine_destroy(h); fprintf(stderr, "goicp_engine_create: %s\n", m.c_str()); return rc_; } } while (0)
 #define CRH(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { fprintf(stderr, "goicp_engine_create: %s: %s\n", #call, hipGetErrorString(e_)); goicp_engine_destroy(h); return GOICP_ERR_NO_DEVICE; } } while (0)
     CRH(hipSetDevice(h->device));
@@ -1800,7 +2178,8 @@ extern "C" int goicp_engine_create(const goicp_engine_desc* d, goicp_engine** ou
     T.NdP = (d->Nd + 1023) & ~1023; T.srot = nullptr; T.srows = nullptr;
     T.exact = (d->parity_mode && d->Nd <= 1024) ? 1 : 0;   // 2*TC*Nd floats of LDS next to the static tile state and the LDS heap
     const size_t ncell = (size_t)d->S * d->S * d->S;
-    float* p_dist; CR(dev_upload(h, d->dt_dist, ncell, &p_dist)); T.dist = p_dist;
+    if (sparse) T.dist = (const float*)d->dt_dist_dev;        // adopted in place (owned by the caller's goicp_dtgpu handle)
+    else { float* p_dist; CR(dev_upload(h, d->dt_dist, ncell, &p_dist)); T.dist = p_dist; }
     float* p_dxyz; CR(dev_upload(h, d->data_xyz, (size_t)3 * d->Nd, &p_dxyz)); T.dxyz = p_dxyz;
     float* p_w; CR(dev_upload(h, d->weights, (size_t)d->Nd, &p_w)); T.weights = p_w;
     float* p_mrd; CR(dev_upload(h, d->maxRotDis, (size_t)GOICP_MAXROTLEVEL * d->Nd, &p_mrd)); T.maxRotDis = p_mrd;
@@ -1823,19 +2202,27 @@ extern "C" int goicp_engine_create(const goicp_engine_desc* d, goicp_engine** ou
         // cell masks are formed on the host (a few hundred cells), the S^3-sized gather through nearest_occ runs on the device
         std::vector<int> occ_cells, occ_ptr(1, 0), occ_pts;
         std::vector<uint16_t> occ_mask;
-        for (size_t k = 0; k < ncell; k++) {
-            const int col = d->cell_color[k];
-            if (col == -2) continue;
-            occ_cells.push_back((int)k);
+        auto add_cell = [&](int k, int col, int p0, int p1) {
+            occ_cells.push_back(k);
             uint16_t m = 0;
-            if (col == -1) { for (int p = d->cell_ptr[k]; p < d->cell_ptr[k + 1]; p++) m |= (uint16_t)(1u << mcls[d->cell_idx[p]]); }
+            if (col == -1) { for (int p = p0; p < p1; p++) m |= (uint16_t)(1u << mcls[d->cell_idx[p]]); }
             else if (known_prop(col)) { auto it = cls.find(col); if (it != cls.end()) m = (uint16_t)(1u << it->second); }
             occ_mask.push_back(m);
-            for (int p = d->cell_ptr[k]; p < d->cell_ptr[k + 1]; p++) occ_pts.push_back(d->cell_idx[p]);
+            for (int p = p0; p < p1; p++) occ_pts.push_back(d->cell_idx[p]);
             occ_ptr.push_back((int)occ_pts.size());
+        };
+        if (sparse) { for (int o = 0; o < d->n_occ; o++) add_cell(d->occ_cells[o], d->occ_color[o], d->occ_ptr[o], d->occ_ptr[o + 1]); }
+        else {
+            for (size_t k = 0; k < ncell; k++) {
+                const int col = d->cell_color[k];
+                if (col == -2) continue;
+                add_cell((int)k, col, d->cell_ptr[k], d->cell_ptr[k + 1]);
+            }
         }
         const int nOcc = (int)occ_cells.size();
-        int* p_near; CR(dev_upload(h, d->nearest_occ, ncell, &p_near));
+        int* p_near;
+        if (sparse) p_near = (int*)d->nearest_occ_dev;            // read-only here
+        else CR(dev_upload(h, d->nearest_occ, ncell, &p_near));
         int* p_occid; CR(dev_upload<int>(h, nullptr, ncell, &p_occid));
         int* p_cells; CR(dev_upload(h, occ_cells.data(), (size_t)nOcc, &p_cells));
         uint16_t* p_om; CR(dev_upload(h, occ_mask.data(), (size_t)nOcc, &p_om));
@@ -1889,7 +2276,7 @@ extern "C" int goicp_engine_create(const goicp_engine_desc* d, goicp_engine** ou
     CR(dev_upload<float>(h, nullptr, (size_t)3 * h->lat_cap, &h->d_lat));
     CR(dev_upload<int>(h, nullptr, h->lat_cap, &h->d_cnt));
     CR(dev_upload<float>(h, nullptr, h->lat_cap, &h->d_fp));
-    { unsigned long long* p_t; CR(dev_upload<unsigned long long>(h, nullptr, 8, &p_t)); CRH(hipMemset(p_t, 0, 64)); T.dbg_times = p_t; }
+    { unsigned long long* p_t; CR(dev_upload<unsigned long long>(h, nullptr, 16, &p_t)); CRH(hipMemset(p_t, 0, 128)); T.dbg_times = p_t; }
     pick_geometry(h);
     if (h->dyn_lds_bnb + sizeof(TileShm<1024>) + 64 > 160 * 1024) { h->err = "LDS budget exceeded"; CR(GOICP_ERR_ARG); }
     {
@@ -1915,6 +2302,17 @@ extern "C" int goicp_engine_create(const goicp_engine_desc* d, goicp_engine** ou
             else DISPATCH_GEOM(h, OCC);
 #undef OCC
             h->resident_jobs = std::max(1, nb) * std::max(1, ncu);
+            // searches of more than 1024 points without penalty terms run round by round over many workgroups (k_fr_*)
+            h->fr_mode = 0; h->fr_nsplit = 1; h->fr_ppt = 4; h->fr_block = 512; h->fr_wgs = 2 * std::max(1, ncu); h->fr_heap_cap = 8192;
+            h->fr_depth2 = !(getenv("GOICP_FR_DEPTH") && atoi(getenv("GOICP_FR_DEPTH")) == 1);      // A/B knob, read once per engine
+            const bool fr_off = getenv("GOICP_FR") && atoi(getenv("GOICP_FR")) == 0;          // A/B knob, read once per engine
+            if (!fr_off && !T.exact && !T.use_compat && !T.use_fpfh && d->Nd > 1024) {
+                if (!h->streamed) { h->fr_mode = 1; h->fr_block = 512; h->fr_ppt = d->Nd <= 2048 ? 4 : (d->Nd <= 4096 ? 8 : 10); h->fr_wgs = 2 * std::max(1, ncu); }
+                else if (T.doTrim) { h->fr_mode = 2; h->fr_block = d->Nd > 16384 ? 1024 : 512; h->fr_wgs = (h->fr_block == 512 ? 2 : 1) * std::max(1, ncu); }
+                else { h->fr_mode = 3; h->fr_block = 1024; h->fr_nsplit = std::min(16, std::max(1, (d->Nd + 6143) / 6144)); h->fr_wgs = std::max(1, ncu); }
+                { const char* e = getenv("GOICP_HEAP_CAP"); if (e && atoi(e) >= 16) h->fr_heap_cap = atoi(e); }
+                h->resident_jobs = std::max(h->resident_jobs, 32);
+            }
         }
     }
 #undef CR
@@ -1926,7 +2324,7 @@ extern "C" int goicp_engine_create(const goicp_engine_desc* d, goicp_engine** ou
 extern "C" int goicp_engine_debug_times(goicp_engine* h, unsigned long long* out8) {
     if (!h || !out8) return GOICP_ERR_ARG;
     HIPCHK(h, hipStreamSynchronize(h->stream));
-    HIPCHK(h, hipMemcpy(out8, h->T.dbg_times, 64, hipMemcpyDeviceToHost));
+    HIPCHK(h, hipMemcpy(out8, h->T.dbg_times, 128, hipMemcpyDeviceToHost));      /* 16 words */
     return GOICP_OK;
 }
 
@@ -1945,6 +2343,13 @@ extern "C" int goicp_engine_stats(const goicp_engine* h, uint64_t* cube_evals, u
     if (cube_evals) *cube_evals = h->n_cubes;
     if (lookups) *lookups = h->n_lookups;
     if (kernel_ms) *kernel_ms = h->kernel_ms;
+    return GOICP_OK;
+}
+
+extern "C" int goicp_engine_search_stats(const goicp_engine* h, uint64_t* rounds, uint64_t* cube_evals_launched) {
+    if (!h) return GOICP_ERR_ARG;
+    if (rounds) *rounds = h->fr_rounds;
+    if (cube_evals_launched) *cube_evals_launched = h->fr_spec_cubes;
     return GOICP_OK;
 }
 
@@ -2143,6 +2548,101 @@ static int run_bnb(goicp_engine* h, const goicp_bnb_job* jobs, int njobs, goicp_
     return GOICP_OK;
 }
 
+// ---- round-based search: buffers, launch loop ------------------------------------------------------------------
+#define FR_KMAX 16
+#define FR_ROUNDS_MAX 64
+static int ensure_fr(goicp_engine* h, size_t jobs, size_t cap, size_t ecap) {
+    // per-search arrays (state, results, rotated cloud, work list) grow with the number of searches; the queue and expansion slabs
+    // with searches x capacity (a search that outgrew its slab is re-run alone on a larger one: few searches, large capacity)
+    if (jobs > h->fr_jobs) {
+        HIPCHK(h, hipStreamSynchronize(h->stream));
+        { void* fr[] = {h->fr_st, h->fr_wl, h->fr_srot, h->fr_results}; for (void* p : fr) if (p) cache_free(p); }
+        h->fr_st = nullptr; h->fr_wl = nullptr; h->fr_srot = nullptr; h->fr_results = nullptr; h->fr_jobs = 0;
+        const size_t wl_cap = std::min<size_t>(jobs * FR_KMAX * 9 * (size_t)h->fr_nsplit * 2, (size_t)1 << 26);
+        HIPCHK(h, cache_malloc((void**)&h->fr_st, jobs * sizeof(FrState), h->device));
+        HIPCHK(h, cache_malloc((void**)&h->fr_results, jobs * sizeof(goicp_bnb_result), h->device));
+        HIPCHK(h, cache_malloc((void**)&h->fr_wl, wl_cap * sizeof(FrItem), h->device));
+        HIPCHK(h, cache_malloc((void**)&h->fr_srot, jobs * (size_t)h->T.NdP * sizeof(float4), h->device));
+        h->fr_jobs = jobs; h->fr_wl_cap = (int)wl_cap;
+    }
+    if (!h->fr_cnt) HIPCHK(h, cache_malloc((void**)&h->fr_cnt, 2 * FR_ROUNDS_MAX * sizeof(unsigned), h->device));
+    if (jobs * cap > h->fr_cap_nodes) {
+        HIPCHK(h, hipStreamSynchronize(h->stream));
+        if (h->fr_heaps) cache_free(h->fr_heaps);
+        h->fr_heaps = nullptr; h->fr_cap_nodes = 0;
+        HIPCHK(h, cache_malloc((void**)&h->fr_heaps, jobs * cap * sizeof(HeapNodeX), h->device));
+        h->fr_cap_nodes = jobs * cap;
+    }
+    if (jobs * ecap > h->fr_cap_exps) {
+        HIPCHK(h, hipStreamSynchronize(h->stream));
+        { void* fr[] = {h->fr_exps, h->fr_parts}; for (void* p : fr) if (p) cache_free(p); }
+        h->fr_exps = nullptr; h->fr_parts = nullptr; h->fr_cap_exps = 0;
+        HIPCHK(h, cache_malloc((void**)&h->fr_exps, jobs * ecap * sizeof(FrExp), h->device));
+        if (h->fr_mode == 3) HIPCHK(h, cache_malloc((void**)&h->fr_parts, jobs * ecap * (size_t)h->fr_nsplit * 16 * sizeof(double), h->device));
+        h->fr_cap_exps = jobs * ecap;
+    }
+    return GOICP_OK;
+}
+
+static void launch_fr_expand(goicp_engine* h, const FrCtx& C, int round, int max_items) {
+    const dim3 grid((unsigned)(h->fr_mode == 2 ? std::min(h->fr_wgs, max_items) : max_items));
+#define FRX(B, P, M, NTT) hipLaunchKernelGGL((k_fr_expand<B, P, M, NTT>), grid, dim3(B), 0, h->stream, h->T, C, round)
+    if (h->fr_mode == 1) { if (h->fr_ppt == 4) FRX(512, 4, 0, 4); else if (h->fr_ppt == 8) FRX(512, 8, 0, 4); else FRX(512, 10, 0, 4); }
+    else if (h->fr_mode == 2) { if (h->fr_block == 512) FRX(512, 1, 1, 8); else FRX(1024, 1, 1, 8); }
+    else FRX(1024, 1, 2, 8);
+#undef FRX
+}
+
+// njobs searches, round by round. `cap` = queue / expansion-slot capacity per search.
+static int run_fr(goicp_engine* h, const goicp_bnb_job* jobs, int njobs, goicp_bnb_result* results, int cap) {
+    // expansion records per search: speculation (several nodes per round, two levels deep) consumes them faster than the queue grows
+    const int ecap = (int)std::min<long long>((long long)cap * (njobs <= 128 ? 8 : 2), 1ll << 27);
+    int rc = ensure_fr(h, (size_t)njobs, (size_t)cap, (size_t)ecap);
+    if (rc != GOICP_OK) return rc;
+    if (h->fr_mode == 2) { rc = ensure_stream_scratch(h, (size_t)h->fr_wgs, false); if (rc != GOICP_OK) return rc; }
+    HIPCHK(h, hipMemcpyAsync(h->d_jobs, jobs, (size_t)njobs * sizeof(goicp_bnb_job), hipMemcpyHostToDevice, h->stream));
+    FrCtx C;
+    C.jobs = h->d_jobs; C.st = h->fr_st; C.results = h->fr_results; C.heaps = h->fr_heaps; C.heap_cap = cap; C.exps = h->fr_exps; C.exp_cap = ecap;
+    C.wl = h->fr_wl; C.wl_cap = h->fr_wl_cap; C.wl_count = h->fr_cnt; C.active = h->fr_cnt + FR_ROUNDS_MAX; C.parts = h->fr_parts; C.nsplit = h->fr_nsplit; C.ngroups = h->fr_mode == 1 ? 2 : 1;
+    C.srot = h->fr_srot; C.NdP = h->T.NdP; C.max_pops = h->max_pops; C.dbg = (h->T.dbg & 32) ? h->T.dbg_times : nullptr;
+    HIPCHK(h, hipEventRecord(h->ev0, h->stream));
+    hipLaunchKernelGGL(k_fr_init, dim3(njobs), dim3(256), 0, h->stream, h->T, C);
+    HIPCHK(h, hipGetLastError());
+    unsigned* host_active = h->pinned ? (unsigned*)h->pinned : nullptr;
+    unsigned active = (unsigned)njobs, active_tmp = 0;
+    int rounds = 4;
+    const int per_tile = h->fr_nsplit * C.ngroups;
+    const int target = 4 * h->fr_wgs;                     // work items per round the chip absorbs without queueing for long
+    for (int batch = 0; active > 0; batch++) {
+        // few live searches: every chosen node is expanded two levels deep (9 tiles) and up to FR_KMAX nodes are chosen per search;
+        // many live searches: one level, as many nodes as still fit the target
+        int depth = ((long long)active * 9 * per_tile <= target && h->fr_depth2) ? 2 : 1;
+        const int slots = depth == 2 ? 9 : 1;
+        const int K = std::max(1, std::min(FR_KMAX, target / (int)std::max(1ll, (long long)active * slots * per_tile)));
+        HIPCHK(h, hipMemsetAsync(h->fr_cnt, 0, 2 * FR_ROUNDS_MAX * sizeof(unsigned), h->stream));
+        for (int r = 0; r < rounds; r++) {
+            hipLaunchKernelGGL(k_fr_select, dim3(njobs), dim3(FR_SELECT_THREADS), 0, h->stream, C, r, K, depth);
+            launch_fr_expand(h, C, r, (int)std::min<long long>((long long)active * K * slots * per_tile, (long long)C.wl_cap));
+        }
+        HIPCHK(h, hipGetLastError());
+        h->fr_rounds += (uint64_t)rounds;
+        if (host_active) { HIPCHK(h, hipMemcpyAsync(host_active, C.active + (rounds - 1), sizeof(unsigned), hipMemcpyDeviceToHost, h->stream)); }
+        else HIPCHK(h, hipMemcpyAsync(&active_tmp, C.active + (rounds - 1), sizeof(unsigned), hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(h, hipStreamSynchronize(h->stream));
+        active = host_active ? *host_active : active_tmp;
+        rounds = std::min(32, rounds * 2);
+        if (batch > 100000) return fail(h, GOICP_ERR_HIP, "round-based search did not terminate");
+    }
+    HIPCHK(h, hipEventRecord(h->ev1, h->stream));
+    HIPCHK(h, hipMemcpyAsync(results, h->fr_results, (size_t)njobs * sizeof(goicp_bnb_result), hipMemcpyDeviceToHost, h->stream));
+    std::vector<FrState> sts((size_t)njobs);
+    HIPCHK(h, hipMemcpyAsync(sts.data(), h->fr_st, (size_t)njobs * sizeof(FrState), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    for (const FrState& st : sts) h->fr_spec_cubes += st.spec;          // cube evaluations launched, consumed by the replay or not
+    float ms = 0.f; (void)hipEventElapsedTime(&ms, h->ev0, h->ev1); h->kernel_ms += ms;
+    return GOICP_OK;
+}
+
 extern "C" int goicp_engine_inner_bnb_batch(goicp_engine* h, const goicp_bnb_job* jobs, int njobs, goicp_bnb_result* results) {
     if (!h || njobs < 0 || (njobs && (!jobs || !results))) return GOICP_ERR_ARG;
     HIPCHK(h, hipSetDevice(h->device));
@@ -2151,20 +2651,27 @@ extern "C" int goicp_engine_inner_bnb_batch(goicp_engine* h, const goicp_bnb_job
     const int job_cap = h->streamed ? std::min(h->job_cap, 256) : h->job_cap;
     for (int off = 0; off < njobs; off += job_cap) {
         const int m = std::min(job_cap, njobs - off);
-        int rc = ensure_heaps(h, (size_t)m);
-        if (rc != GOICP_OK) return rc;
-        rc = run_bnb(h, jobs + off, m, results + off, h->d_heaps, h->heap_cap);
+        int rc;
+        if (h->fr_mode) rc = run_fr(h, jobs + off, m, results + off, h->fr_heap_cap);
+        else {
+            rc = ensure_heaps(h, (size_t)m);
+            if (rc != GOICP_OK) return rc;
+            rc = run_bnb(h, jobs + off, m, results + off, h->d_heaps, h->heap_cap);
+        }
         if (rc != GOICP_OK) return rc;
         for (int j = 0; j < m; j++) {
             goicp_bnb_result& r = results[off + j];
             // a job whose queue outgrew its slab is re-run alone on a larger one (the search is deterministic); jobs that carry a
             // pop budget are speculative and are simply reported as overflowed
-            int cap = h->heap_cap;
+            int cap = h->fr_mode ? h->fr_heap_cap : h->heap_cap;
             while (r.status == GOICP_ERR_OVERFLOW && jobs[off + j].max_pops == 0 && cap < (1 << 26)) {
                 cap *= 16;
-                rc = ensure_big_heap(h, cap);
-                if (rc != GOICP_OK) return rc;
-                rc = run_bnb(h, jobs + off + j, 1, &r, h->d_heap_big, cap);
+                if (h->fr_mode) rc = run_fr(h, jobs + off + j, 1, &r, cap);
+                else {
+                    rc = ensure_big_heap(h, cap);
+                    if (rc != GOICP_OK) return rc;
+                    rc = run_bnb(h, jobs + off + j, 1, &r, h->d_heap_big, cap);
+                }
                 if (rc != GOICP_OK) return rc;
             }
             h->n_cubes += r.cube_evals; h->n_lookups += (uint64_t)r.cube_evals * h->T.Nd;

@@ -62,6 +62,16 @@ public:
     std::vector<int32_t> cell_color;       // [S^3] cellPoints[].c  (-2 empty, -1 mixed after assignCellColor)
     std::vector<int32_t> cell_ptr;         // [S^3+1] CSR of cellPoints[].points
     std::vector<int32_t> cell_idx;
+    // --- addition of this build: the exact transform built and kept on the device (csrc/dt_gpu.hip, GoICP::dt_mode = 1). The dense
+    // host vectors above then stay empty; the cell tables exist in sparse form (occupied cells only) and cell_idx is shared.
+    goicp_dtgpu* gpu = nullptr;
+    std::vector<int32_t> occ_cells, occ_color, occ_ptr;
+    int BuildGpu(const double* x, const double* y, const double* z, int num, int device);   // GOICP_* status
+    void ReleaseGpu();
+    DT3D() {}
+    ~DT3D() { ReleaseGpu(); }
+    DT3D(const DT3D&) = delete;
+    DT3D& operator=(const DT3D&) = delete;
 };
 
 struct RegisterStats {
@@ -107,6 +117,7 @@ public:
     // --- additions of this build (not in the reference) ---
     int device_id = 0;
     int parity_mode = 1;          // see goicp_engine_desc::parity_mode
+    int dt_mode = 0;              // 0: DT3D::Build restated on the host (bit-identical to the reference grid); 1: exact Euclidean transform built on the device (opt-in, see csrc/dt_gpu.hip)
     int speculate = 128;           // 0: one InnerBnB per launch; 1: the <=16 calls of a rotation pop per launch; M>1: also those of the next M-1 queue nodes
     uint32_t spec_pop_budget = 20000;   // queue-pop budget of a speculative job (re-run unbounded if it turns out to be needed)
     int verbose = 0;              // echo the reference's "Error*: ..." progress lines to stdout

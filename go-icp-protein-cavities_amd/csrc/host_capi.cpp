@@ -78,6 +78,7 @@ int goicp_load_dt(goicp_handle* h, int S, const double* g4, const float* dist, c
                   const int32_t* cell_ptr, const int32_t* cell_idx) {
     if (!h || S <= 0 || !g4 || !dist) return GOICP_ERR_ARG;
     DT3D& d = h->g.dt;
+    d.ReleaseGpu();
     const size_t n = (size_t)S * S * S;
     d.SIZE = S; d.xMin = g4[0]; d.yMin = g4[1]; d.zMin = g4[2]; d.scale = g4[3];
     d.xMax = d.xMin + S / d.scale; d.yMax = d.yMin + S / d.scale; d.zMax = d.zMin + S / d.scale;
@@ -97,9 +98,21 @@ int goicp_dt_geom(goicp_handle* h, double* g) {
     g[0] = d.xMin; g[1] = d.xMax; g[2] = d.yMin; g[3] = d.yMax; g[4] = d.zMin; g[5] = d.zMax; g[6] = d.scale; g[7] = d.SIZE;
     return GOICP_OK;
 }
+int goicp_set_dt_mode(goicp_handle* h, int mode) { if (!h || (mode != 0 && mode != 1)) return GOICP_ERR_ARG; h->g.dt_mode = mode; return GOICP_OK; }
+
 int goicp_dt_dump(goicp_handle* h, float* dist, int32_t* nearest, int32_t* cell_color) {
     if (!h) return GOICP_ERR_ARG;
     const DT3D& d = h->g.dt;
+    if (d.gpu) {
+        const int rc = goicp_dtgpu_download(d.gpu, dist, nearest);
+        if (rc != GOICP_OK) return rc;
+        if (cell_color) {
+            const size_t n = (size_t)d.SIZE * d.SIZE * d.SIZE;
+            for (size_t k = 0; k < n; k++) cell_color[k] = -2;
+            for (size_t o = 0; o < d.occ_cells.size(); o++) cell_color[d.occ_cells[o]] = d.occ_color[o];
+        }
+        return GOICP_OK;
+    }
     if (dist) std::memcpy(dist, d.dist.data(), d.dist.size() * sizeof(float));
     if (nearest) std::memcpy(nearest, d.nearest.data(), d.nearest.size() * sizeof(int32_t));
     if (cell_color) std::memcpy(cell_color, d.cell_color.data(), d.cell_color.size() * sizeof(int32_t));

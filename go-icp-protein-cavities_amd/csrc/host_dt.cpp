@@ -271,4 +271,59 @@ void DT3D::Build(const double* _x, const double* _y, const double* _z, int num) 
     }
 }
 
+
+// ---- dt_mode 1: exact transform on the device ---------------------------------------------------------------------------------
+void DT3D::ReleaseGpu() {
+    if (gpu) { goicp_dtgpu_destroy(gpu); gpu = nullptr; }
+}
+
+int DT3D::BuildGpu(const double* _x, const double* _y, const double* _z, int num, int device) {
+    ReleaseGpu();
+    dist.clear(); nearest.clear(); cell_color.clear(); cell_ptr.clear();
+    const int S = SIZE;
+    if (num <= 0 || S < 1) return GOICP_ERR_ARG;
+    // grid geometry: reference jly_3ddt.cpp:899-930 (same expressions as DT3D::Build above)
+    xMin = xMax = _x[0]; yMin = yMax = _y[0]; zMin = zMax = _z[0];
+    for (int i = 1; i < num; i++) {
+        if (xMin > _x[i]) xMin = _x[i];
+        if (xMax < _x[i]) xMax = _x[i];
+        if (yMin > _y[i]) yMin = _y[i];
+        if (yMax < _y[i]) yMax = _y[i];
+        if (zMin > _z[i]) zMin = _z[i];
+        if (zMax < _z[i]) zMax = _z[i];
+    }
+    const double xC = (xMin + xMax) / 2, yC = (yMin + yMax) / 2, zC = (zMin + zMax) / 2;
+    xMin = xC - expandFactor * (xMax - xC); xMax = xC + expandFactor * (xMax - xC);
+    yMin = yC - expandFactor * (yMax - yC); yMax = yC + expandFactor * (yMax - yC);
+    zMin = zC - expandFactor * (zMax - zC); zMax = zC + expandFactor * (zMax - zC);
+    double mx = xMax - xMin > yMax - yMin ? xMax - xMin : yMax - yMin;
+    mx = mx > zMax - zMin ? mx : zMax - zMin;
+    xMin = xC - mx / 2; xMax = xC + mx / 2;
+    yMin = yC - mx / 2; yMax = yC + mx / 2;
+    zMin = zC - mx / 2; zMax = zC + mx / 2;
+    scale = S / mx;
+    // seed cells ROUND((p - min) * scale) (jly_3ddt.cpp:976-995) and their point lists, occupied cells in ascending order
+    std::vector<std::pair<int32_t, int32_t>> cp; cp.reserve((size_t)num);
+    for (int i = 0; i < num; i++) {
+        const int x = (int)((_x[i] - xMin) * scale + 0.5), y = (int)((_y[i] - yMin) * scale + 0.5), z = (int)((_z[i] - zMin) * scale + 0.5);
+        if ((unsigned)x >= (unsigned)S || (unsigned)y >= (unsigned)S || (unsigned)z >= (unsigned)S) continue;
+        cp.emplace_back((int32_t)(((size_t)z * S + y) * S + x), (int32_t)i);
+    }
+    std::stable_sort(cp.begin(), cp.end(), [](const std::pair<int32_t, int32_t>& a, const std::pair<int32_t, int32_t>& b) { return a.first < b.first; });
+    occ_cells.clear(); occ_ptr.assign(1, 0); cell_idx.clear(); occ_color.clear();
+    for (size_t k = 0; k < cp.size(); k++) {
+        if (occ_cells.empty() || occ_cells.back() != cp[k].first) { if (!occ_cells.empty()) occ_ptr.push_back((int32_t)cell_idx.size()); occ_cells.push_back(cp[k].first); }
+        cell_idx.push_back(cp[k].second);
+    }
+    occ_ptr.push_back((int32_t)cell_idx.size());
+    occ_color.assign(occ_cells.size(), -1);
+    if (occ_cells.empty()) return GOICP_ERR_ARG;
+    if (cell_idx.empty()) cell_idx.push_back(0);
+    // value per squared cell distance: float((double)(float)sqrt((double)d2) / scale)   (jly_3ddt.cpp:28,79,1003)
+    const int nt = 3 * (S - 1) * (S - 1) + 1;
+    std::vector<float> table((size_t)nt);
+    for (int n = 0; n < nt; n++) table[(size_t)n] = (float)((double)(float)std::sqrt((double)n) / scale);
+    return goicp_dtgpu_build(device, S, occ_cells.data(), (int)occ_cells.size(), table.data(), nt, &gpu);
+}
+
 }  // namespace goicp

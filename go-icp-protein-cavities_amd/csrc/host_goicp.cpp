@@ -211,16 +211,33 @@ void GoICP::log_error(const char* tag, float v) {
 
 // reference jly_goicp.cpp:79-99 + assignCellColor (:951-969)
 void GoICP::BuildDT() {
+    status = GOICP_OK; error_message.clear();
     for (int i = 0; i < Nm; i++) if (!std::isfinite(pModel[i].x) || !std::isfinite(pModel[i].y) || !std::isfinite(pModel[i].z)) {
         status = GOICP_ERR_ARG; error_message = "model cloud holds a non-finite coordinate"; return;
     }
     std::vector<double> x(Nm), y(Nm), z(Nm);
     for (int i = 0; i < Nm; i++) { x[i] = pModel[i].x; y[i] = pModel[i].y; z[i] = pModel[i].z; }
-    dt.Build(x.data(), y.data(), z.data(), Nm);
+    if (dt_mode == 1) {
+        status = dt.BuildGpu(x.data(), y.data(), z.data(), Nm, device_id);
+        if (status != GOICP_OK) { error_message = status == GOICP_ERR_NO_DEVICE ? "no usable HIP device for the device DT build" : "device DT build failed"; return; }
+    } else {
+        dt.ReleaseGpu();
+        dt.Build(x.data(), y.data(), z.data(), Nm);
+    }
     assignCellColor();
 }
 
 void GoICP::assignCellColor() {
+    if (dt.gpu) {               // sparse tables of the device-built grid
+        for (size_t o = 0; o < dt.occ_cells.size(); o++) {
+            const int p0 = dt.occ_ptr[o], p1 = dt.occ_ptr[o + 1];
+            const int prop = pModel[dt.cell_idx[p0]].c;
+            bool mixed = false;
+            for (int p = p0 + 1; p < p1; p++) if (pModel[dt.cell_idx[p]].c != prop) { mixed = true; break; }
+            dt.occ_color[o] = mixed ? -1 : prop;
+        }
+        return;
+    }
     const size_t ncell = dt.cell_color.size();
     for (size_t k = 0; k < ncell; k++) if (dt.cell_color[k] == -1) {
         const int p0 = dt.cell_ptr[k], p1 = dt.cell_ptr[k + 1];
@@ -349,8 +366,13 @@ void GoICP::Initialize() {
     goicp_engine_desc d;
     std::memset(&d, 0, sizeof d);
     d.S = dt.SIZE; d.xMin = dt.xMin; d.yMin = dt.yMin; d.zMin = dt.zMin; d.scale = dt.scale;
-    d.dt_dist = dt.dist.data();
-    d.nearest_occ = dt.nearest.data(); d.cell_color = dt.cell_color.data(); d.cell_ptr = dt.cell_ptr.data(); d.cell_idx = dt.cell_idx.data();
+    if (dt.gpu) {               // device-resident grid: adopted in place, sparse cell tables
+        d.dt_dist_dev = goicp_dtgpu_dist(dt.gpu); d.nearest_occ_dev = goicp_dtgpu_nearest(dt.gpu);
+        d.n_occ = (int32_t)dt.occ_cells.size(); d.occ_cells = dt.occ_cells.data(); d.occ_color = dt.occ_color.data(); d.occ_ptr = dt.occ_ptr.data(); d.cell_idx = dt.cell_idx.data();
+    } else {
+        d.dt_dist = dt.dist.data();
+        d.nearest_occ = dt.nearest.data(); d.cell_color = dt.cell_color.data(); d.cell_ptr = dt.cell_ptr.data(); d.cell_idx = dt.cell_idx.data();
+    }
     d.Nm = Nm; d.model_xyz = mxyz.data(); d.model_color = mcol.data(); d.model_fpfh = need_fpfh ? mf.data() : nullptr;
     d.Nd = Nd; d.data_xyz = dxyz.data(); d.data_color = dcol.data(); d.data_fpfh = need_fpfh ? df.data() : nullptr;
     d.weights = weights.data(); d.maxRotDis = maxRotDis.data();
@@ -738,7 +760,12 @@ float GoICP::Register() {
     if (!eng_) return std::numeric_limits<float>::quiet_NaN();
     OuterBnB();
     const double t2 = now_ms();
-    if (timing) fprintf(stderr, "[goicp timing] Initialize+engine %.1f ms, OuterBnB %.1f ms (ICP host+device %.1f ms)\n", t1 - t0, t2 - t1, icp_ms_);
+    if (timing) {
+        uint64_t rounds = 0, launched = 0;
+        goicp_engine_search_stats(eng_, &rounds, &launched);
+        fprintf(stderr, "[goicp timing] Initialize+engine %.1f ms, OuterBnB %.1f ms (ICP host+device %.1f ms); search rounds %llu, cube evals launched %llu, consumed %llu\n",
+                t1 - t0, t2 - t1, icp_ms_, (unsigned long long)rounds, (unsigned long long)launched, (unsigned long long)stats.cube_evals);
+    }
     double ms = 0; uint64_t ce = 0, lk = 0;
     goicp_engine_stats(eng_, &ce, &lk, &ms);
     stats.engine_kernel_ms = ms;

@@ -28,6 +28,10 @@ int goicp_set_clouds(goicp_handle*, int Nm, const float* mxyz, const int32_t* mc
 int goicp_set_nd(goicp_handle*, int Nd);                        /* goicp.Nd = NdDownsampled, reference jly_main.cpp:114-117 */
 
 int goicp_build_dt(goicp_handle*);                              /* GoICP::BuildDT */
+/* 0 (default): DT3D::Build restated on the host, bit-identical to the reference grid (reference jly_3ddt.cpp:897-1137);
+ * 1: exact Euclidean transform built and kept on the device (goicp_dtgpu_build, include/goicp_engine.h) -- opt-in, differs from the
+ *    reference's propagated approximation in a few cells */
+int goicp_set_dt_mode(goicp_handle*, int mode);
 /* adopt externally built tables instead (geom4 = xMin,yMin,zMin,scale; nearest = linear cell index) */
 int goicp_load_dt(goicp_handle*, int S, const double* geom4, const float* dist, const int32_t* nearest,
                   const int32_t* cell_color, const int32_t* cell_ptr, const int32_t* cell_idx);

@@ -81,6 +81,15 @@ typedef struct goicp_engine_desc {
      *    back to 0.  0: order-free fp64 sums and an exact histogram selection (same inlier multiset; bounds within n*eps of
      *    the reference, so a search may settle on a different epsilon-optimal node). */
     int32_t parity_mode;
+    /* Optional device-resident grid (built by goicp_dtgpu_build below): when dt_dist_dev is non-NULL the engine adopts these
+     * buffers in place -- nothing is copied or uploaded, and they must outlive the engine; dt_dist / nearest_occ / cell_color /
+     * cell_ptr are then ignored and the cell tables come in sparse form (occupied cells only). */
+    const void*    dt_dist_dev;    /* device float[S^3] */
+    const void*    nearest_occ_dev;/* device int32[S^3]: linear index of the nearest occupied cell */
+    int32_t        n_occ;          /* occupied cells */
+    const int32_t* occ_cells;      /* [n_occ] linear cell index, ascending */
+    const int32_t* occ_color;      /* [n_occ] -1 mixed, else property code (cellPoints[].c after assignCellColor) */
+    const int32_t* occ_ptr;        /* [n_occ+1] CSR offsets into cell_idx */
 } goicp_engine_desc;
 
 typedef struct goicp_bnb_job {
@@ -143,10 +152,26 @@ int goicp_engine_icp_nn_ties(goicp_engine* h, const double* R9, const double* t3
 int goicp_engine_synchronize(goicp_engine* h);
 /* cumulative counters since create: cube evaluations, point lookups, kernel milliseconds (HIP events) */
 int goicp_engine_stats(const goicp_engine* h, uint64_t* cube_evals, uint64_t* lookups, double* kernel_ms);
+/* round-based searches (clouds above 1024 points, geometric error): select/expand rounds launched so far and cube evaluations
+ * launched by them (>= the evaluations the replay consumed: the difference is speculation that was not needed); 0 otherwise */
+int goicp_engine_search_stats(const goicp_engine* h, uint64_t* rounds, uint64_t* cube_evals_launched);
 /* name of the cube-sweep kernel instantiation goicp_engine_eval_cubes* launches for this handle (as profilers print it) */
 const char* goicp_engine_eval_kernel_name(goicp_engine* h);
 /* opaque hipStream_t of the handle, for callers that time with their own HIP events */
 void* goicp_engine_stream(const goicp_engine* h);
+
+/* ---- exact distance transform on the device (opt-in, NOT bit-identical to DT3D::Build) -----------------
+ * The reference's DT3D::Build (reference jly_3ddt.cpp:897-1137) is a sequential vector propagation that approximates the
+ * Euclidean transform; this builds the exact one (separable, integer squared distances) with the same geometry, seeds and
+ * stored value: dist[cell] = dist_of_d2[d2] where d2 = squared cell distance to the nearest occupied cell and the table holds
+ * float((double)(float)sqrt((double)d2) / scale) (jly_3ddt.cpp:28,79,1003) computed by the caller; nearest[cell] = linear index
+ * of that occupied cell (the emptyCells map of jly_3ddt.cpp:1012-1132). occ_cells = linear indices of the occupied cells. */
+typedef struct goicp_dtgpu goicp_dtgpu;
+int  goicp_dtgpu_build(int device_id, int S, const int32_t* occ_cells, int n_occ, const float* dist_of_d2, int n_table, goicp_dtgpu** out);
+const void* goicp_dtgpu_dist(const goicp_dtgpu* h);       /* device float[S^3] */
+const void* goicp_dtgpu_nearest(const goicp_dtgpu* h);    /* device int32[S^3] */
+int  goicp_dtgpu_download(const goicp_dtgpu* h, float* dist, int32_t* nearest);   /* either may be NULL */
+void goicp_dtgpu_destroy(goicp_dtgpu* h);
 
 /* ---- point-weight precompute (GoICP::neighborsWeights, reference jly_goicp.cpp:1453-1498) ----
  * counts[i] = #{ j != i : ||p_j - p_i|| < lim } with the reference's float/double mixing; one call per radius step. */

@@ -28,5 +28,18 @@ def _build_oracle():
     yield
 
 
+@pytest.fixture(scope="session", autouse=True)
+def _torch_gpu_first():
+    """On a GPU box: let torch bring its (bundled) HIP runtime up before the engine library's runtime has created streams and
+    parked gigabytes of device memory in the same process; tests that hand torch buffers to the engine then find it initialised."""
+    try:
+        import torch
+        if torch.cuda.is_available():
+            torch.zeros(1, device="cuda")
+    except Exception:
+        pass
+    yield
+
+
 def have_ref():
     return os.path.exists(os.path.join(ROOT, "oracle", "_ref", "libgoicp_ref.so"))

@@ -233,6 +233,42 @@ def test_speculative_batching_does_not_change_the_result():
     assert outs[2]["stats"]["inner_launches"] < outs[1]["stats"]["inner_launches"] < outs[0]["stats"]["inner_launches"]
 
 
+@pytest.mark.parametrize("n,S,trim", [(1500, 60, 0.0), (2000, 60, 0.1), (3000, 60, 0.0), (5000, 100, 0.1), (7000, 100, 0.1), (9000, 100, 0.0), (20000, 100, 0.0)])
+def test_round_based_search_equals_the_one_workgroup_search(n, S, trim, monkeypatch):
+    """Clouds above 1024 points: the round-based search (k_fr_select / k_fr_expand: the children of several queue nodes evaluated
+    at once, the reference's pop / prune / push order replayed from the stored bounds) must return what the search that walks
+    its queue in one workgroup (k_inner_bnb, GOICP_FR=0) returns: value, node, found flag, pop count -- speculation only decides
+    when a node's children are evaluated. Also with small queue slabs (overflow -> re-run alone on a larger slab)."""
+    P = synth_pair(n, seed=20260301 + n)
+    v, _ = cfg_vector(distTransSize=S, trimFraction=trim, regularization=0.0, ponderation=0, MSEThresh=0.001)
+    o = oracle_for(P, v); o.initialize()
+    dist, near3, cc, _ = o.dt_dump()
+
+    def engine():
+        return goicp_amd.Engine(S=S, geom4=(o.geom[0], o.geom[2], o.geom[4], o.geom[6]), dist=dist, data_xyz=P["s"], weights=o.weights(),
+                                maxrotdis=o.maxrotdis(), model_xyz=P["t"], inlier_num=o.inlier_num(), do_trim=trim >= 0.001, norm=2, parity_mode=1)
+    rng = np.random.default_rng(n)
+    jobs = []
+    for k in range(24):
+        R = o.axis_angle(rng.uniform(-2, 2, 3).astype(np.float32))
+        jobs.append(dict(R=R, level=int(rng.integers(-1, 5)), E=float(rng.uniform(0.5, 30.0) * n / 1000.0), sse=float(0.001 * o.inlier_num()), init=(-0.5, -0.5, -0.5, 1.0)))
+    jobs += [dict(jobs[3], max_pops=5), dict(jobs[4], max_pops=1)]            # pop budgets (speculative jobs of the outer search)
+    monkeypatch.setenv("GOICP_FR", "0")
+    e0 = engine(); want = e0.inner_bnb_batch(jobs); e0.close()
+    monkeypatch.setenv("GOICP_FR", "1")
+    e1 = engine(); got = e1.inner_bnb_batch(jobs); st = e1.search_stats(); e1.close()
+    monkeypatch.setenv("GOICP_HEAP_CAP", "24")
+    e2 = engine(); got_small = e2.inner_bnb_batch(jobs); e2.close()
+    assert st["rounds"] > 0 and st["cube_evals_launched"] >= sum(r["cube_evals"] for r in got)
+    assert sum(r["pops"] for r in want) > 100                                 # the case exercises real searches
+    for j, a, b, c in zip(jobs, want, got, got_small):
+        for r in (b, c):
+            if r is c and j.get("max_pops") and c["status"] == 4:
+                continue                                                       # a budgeted (speculative) job that outgrows its slab is reported as such, not re-run
+            assert r["status"] == a["status"] and r["val"] == a["val"] and r["found"] == a["found"] and r["pops"] == a["pops"] and r["cube_evals"] == a["cube_evals"]
+            assert np.array_equal(r["node"], a["node"])
+
+
 @pytest.mark.parametrize("n,S,trim", [(1000, 100, 0.0), (1000, 100, 0.1), (5000, 100, 0.1), (3000, 60, 0.0), (2000, 60, 0.1), (1500, 60, 0.0)])
 def test_synthetic_cloud_against_oracle(n, S, trim):
     """Seeded synthetic pair (SURVEY.md 8(d) generator), geometric path: cube tables + InnerBnB vs the oracle."""

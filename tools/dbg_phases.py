@@ -13,7 +13,7 @@ for name, pn in (("pair1_fpfh","pair1"),("pair1_default","pair1"),("pair1_trim",
     tot = np.zeros(8, np.uint64)
     for k in range(len(H["call_level"])):
         r = e.inner_bnb(R=H["call_R"][k], level=int(H["call_level"][k]), E=H["call_E"][k], sse=np.float32(H["sse"]), init=init)
-    out = np.zeros(8, np.uint64)
+    out = np.zeros(16, np.uint64)
     e.L.goicp_engine_debug_times(e.h, out.ctypes.data_as(C.c_void_p))
     pops = int(out[7]); cyc = out[:6].astype(float)
     print(name, "pops", pops, "cycles/pop by phase [pop+ctl, setup, sweep, compat, fpfh, decide+push]:", np.round(cyc / pops).astype(int), "total", int(cyc.sum() / pops), "(s_memtime ticks @100MHz? see note)")
