@@ -196,6 +196,19 @@ def main():
                    cube_evals=out["stats"]["cube_evals"], rot_pops=out["stats"]["rot_pops"], inner_calls=out["stats"]["inner_calls"],
                    inner_launches=out["stats"]["inner_launches"], engine_kernel_ms=out["kernel_ms"],
                    dR_vs_planted=float(np.abs(out["R"] - P["Rtrue"]).max()), dt_vs_planted=float(np.abs(out["t"] - P["ttrue"]).max()))
+        # the same pair with the grid built on the device (opt-in exact transform, csrc/dt_gpu.hip): BuildDT() + Register()
+        g2 = goicp_amd.GoICP(cfg, device_id=local, dt_mode=1); g2.set_clouds(P["t"], P["s"])
+        g2.build_dt()                                     # (first build of the process: code-object load)
+        if use_dist:
+            dist.barrier()
+        t0 = time.perf_counter(); g2.build_dt(); t1 = time.perf_counter(); out2 = g2.register(); t2 = time.perf_counter()
+        g2.close()
+        td = torch.tensor([t2 - t0], dtype=torch.float64, device=dev)
+        if use_dist:
+            dist.all_reduce(td, op=dist.ReduceOp.MAX)
+        reg.update(device_dt=dict(dt_build_seconds=t1 - t0, register_seconds=t2 - t1, pair_registrations_per_sec_incl_dt_build=world / float(td.item()),
+                                  error=float(out2["error"]), dR_vs_planted=float(np.abs(out2["R"] - P["Rtrue"]).max()),
+                                  note="dt_mode=1: exact Euclidean transform built on the GPU (not bit-identical to the reference's propagated grid; opt-in)"))
         if args.overlap_pairs > 1:
             reg.update(overlapped_registrations(goicp_amd, synth_pair, cfg, nd, args.overlap_pairs, local, world, rank, use_dist, dist, dev, torch))
 

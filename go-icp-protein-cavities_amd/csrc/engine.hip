@@ -41,6 +41,9 @@ struct DevTables {
     int S;
     double xMin, yMin, zMin, scale;
     const float* dist;
+    // 2-byte coded copy of the grid (see k_build_codes): code = squared cell distance d2 when dist == lut[d2] bit for bit and d2 < 65535,
+    // else 0xFFFF (the value is then read from `dist`). Twice the cells per cache line of the gather stream; null = not built.
+    const uint16_t* code; const float* lut;
     const uint16_t* cmask;
     const int* occ;          // [S^3] compact id of the nearest occupied cell, -1 if none
     const int* occ_ptr;      // [nOcc+1]
@@ -59,6 +62,8 @@ struct DevTables {
     float4* srot;            // streaming path (Nd > 8192): per-workgroup rotated cloud [NdP]
     float* srows;            // streaming path, trimmed runs: per-workgroup residual rows [TC][NdP]
     int NdP;                 // row pitch of the two above
+    unsigned* cu_tickets;    // [8*256] per-CU arrival counters of the current k_eval_cubes launch (phase stagger), or null
+    int stagger_sleeps;      // s_sleep(127) repetitions (~8 k cycles each) the second workgroup of a CU waits before its first tile
     int dbg;                 // GOICP_DBG ablation bits (diagnosis only; results are wrong when set)
     unsigned long long* dbg_times;   // [8] per-phase cycle sums of job 0, lane 0 (GOICP_DBG & 32)
 };
@@ -112,6 +117,16 @@ __device__ __forceinline__ float dt_lookup(const DevTables& T, float X, float Y,
     float ext;
     const unsigned idx = dt_index(T, X, Y, Z, ext);
     return dt_finish(T, T.dist[idx], ext);
+}
+
+#define LUT_LDS 8192      // leading LUT entries a sweep kernel keeps in LDS (squared cell distances below 8192: within 90 cells of the model)
+// value of cell idx through the coded grid: code -> LUT (LDS copy for small codes, global beyond), escape -> the float grid
+__device__ __forceinline__ float dt_decode(const DevTables& T, unsigned idx, unsigned c, const float* lut_lds) {
+    if (c < (unsigned)LUT_LDS && lut_lds) {
+        const __attribute__((address_space(3))) float* q = (const __attribute__((address_space(3))) float*)lut_lds;
+        return q[c];
+    }
+    return c != 0xFFFFu ? T.lut[c] : T.dist[idx];
 }
 
 __device__ __forceinline__ size_t clamped_cell(const DevTables& T, float X, float Y, float Z) {
@@ -306,7 +321,8 @@ template <int BLOCK, int PPT, bool OCT, int NT, bool JIT = false>
 __device__ __forceinline__ void sweep_tile(const DevTables& T, TileShm<BLOCK>& sh, const float (&px)[PPT], const float (&py)[PPT],
                                            const float (&pz)[PPT], const float (&pw)[PPT], const float (&prho)[PPT], bool use_rho,
                                            float* rbuf /* LDS, exact mode only */, bool row_mode = false /* !OCT: the cubes share y and z */,
-                                           const float4* __restrict__ jit_rot = nullptr, const float* __restrict__ jit_rho = nullptr) {
+                                           const float4* __restrict__ jit_rot = nullptr, const float* __restrict__ jit_rho = nullptr,
+                                           const float* lut_lds = nullptr /* LDS copy of T.lut[0, LUT_LDS) or null */) {
     const int tid = threadIdx.x;
     const int Nd = T.Nd;
     float r[NT][PPT];
@@ -355,6 +371,10 @@ __device__ __forceinline__ void sweep_tile(const DevTables& T, TileShm<BLOCK>& s
         }
         return oob;
     };
+    // diagnosis (GOICP_DBG & 64): cycle stamps of wave 0 / lane 0 of every 64th workgroup, summed into T.dbg_times[0..7]
+    const bool stamp = (T.dbg & 64) && T.dbg_times && tid == 0 && (blockIdx.x & 63) == 0;
+    unsigned long long tl_ = stamp ? clock64() : 0ull;
+#define TSTAMP(k) do { if (stamp) { const unsigned long long now_ = clock64(); atomicAdd(&T.dbg_times[k], now_ - tl_); tl_ = now_; } } while (0)
     float4 pnext = make_float4(0.f, 0.f, 0.f, 0.f); float rnext = 0.f;
     if (JIT) { const int i0 = min(tid, Nd - 1); pnext = jit_rot[i0]; rnext = jit_rho ? jit_rho[i0] : 0.f; }
 #pragma unroll
@@ -366,8 +386,17 @@ __device__ __forceinline__ void sweep_tile(const DevTables& T, TileShm<BLOCK>& s
         } else { X = px[m]; Y = py[m]; Z = pz[m]; W = pw[m]; RH = prho[m]; }
         unsigned idx[NT]; float v[NT];
         const unsigned oob = cells(X, Y, Z, idx);
+        if (T.code) {
+            // coded grid: 2-byte gathers (half the cache lines of the float grid), then the value from the LUT
+            unsigned c[NT];
 #pragma unroll
-        for (int j = 0; j < NT; j++) v[j] = T.dist[(T.dbg & 2) ? (idx[j] & 1023u) : idx[j]];
+            for (int j = 0; j < NT; j++) c[j] = T.code[(T.dbg & 2) ? (idx[j] & 1023u) : idx[j]];
+#pragma unroll
+            for (int j = 0; j < NT; j++) v[j] = dt_decode(T, idx[j], c[j], lut_lds);
+        } else {
+#pragma unroll
+            for (int j = 0; j < NT; j++) v[j] = T.dist[(T.dbg & 2) ? (idx[j] & 1023u) : idx[j]];
+        }
         if (__any((int)oob)) {
 #pragma unroll
             for (int j = 0; j < NT; j++) {
@@ -386,6 +415,7 @@ __device__ __forceinline__ void sweep_tile(const DevTables& T, TileShm<BLOCK>& s
         }
         if (JIT) __builtin_amdgcn_sched_barrier(0);        // keep the point fetches one ahead instead of all up front
     }
+    TSTAMP(0);
     if (BLOCK * PPT <= 1024 && T.exact && T.doTrim) {
         // parity mode, trimmed: residual rows to LDS, one lane per cube runs the reference's selection (same swaps, same final
         // order), then the inlier sums are taken sequentially in float over that order -- bit-exact with jly_goicp.cpp:384-415
@@ -489,6 +519,7 @@ __device__ __forceinline__ void sweep_tile(const DevTables& T, TileShm<BLOCK>& s
             if (ln == 0) sh.wmax[wv][j] = mx;
         }
         __syncthreads();                                                            // barrier 1
+        TSTAMP(1);
         int base16[NT];
 #pragma unroll
         for (int j = 0; j < NT; j++) {
@@ -517,6 +548,7 @@ __device__ __forceinline__ void sweep_tile(const DevTables& T, TileShm<BLOCK>& s
             if (ln == 0 && z) atomicAdd(&sh.zc[j], z);
         }
         __syncthreads();                                                            // barrier 2
+        TSTAMP(2);
         for (int j = wv; j < NT; j += NW) {             // (3) one wave scans the 1024 bins of a cube: 16 per lane
             unsigned c[16]; int mine = 0;
 #pragma unroll
@@ -550,6 +582,7 @@ __device__ __forceinline__ void sweep_tile(const DevTables& T, TileShm<BLOCK>& s
             }
         }
         __syncthreads();                                                            // barrier 3
+        TSTAMP(3);
         if (!sh.fallback) {
             // (4) one pass over the registers: everything below the threshold bin goes into the sums (lane-local float partials
             //     of <= PPT addends, fp64 across lanes), the bin's members (a handful) into the candidate list
@@ -577,6 +610,7 @@ __device__ __forceinline__ void sweep_tile(const DevTables& T, TileShm<BLOCK>& s
                 if (ln == 0) { sh.red[wv][2 * j] = u; sh.red[wv][2 * j + 1] = l; }
             }
             __syncthreads();                                                        // barrier 4
+            TSTAMP(4);
             // (5) wave j finishes cube j: low 16 bits of the threshold by bisection over the candidates, the candidates below it and
             //     the copies of the threshold that belong to the inlier set join the partial sums of all waves
             for (int j = wv; j < NT; j += NW) {
@@ -614,6 +648,8 @@ __device__ __forceinline__ void sweep_tile(const DevTables& T, TileShm<BLOCK>& s
                 }
             }
             __syncthreads();                                                        // barrier 5
+            TSTAMP(5);
+            if (stamp) atomicAdd(&T.dbg_times[7], 1ull);
             return;
         }
         const bool generic = sh.fallback != 0;
@@ -698,6 +734,8 @@ __device__ __forceinline__ void sweep_tile(const DevTables& T, TileShm<BLOCK>& s
     }
     __syncthreads();
 }
+
+#undef TSTAMP
 
 // Penalty terms at the nl translations in sh.lat[]: incompatibility counts (checkCompatibilities, reference
 // jly_goicp.cpp:919-928) into sh.cnt[], c-FPFH means (sumFPFH, jly_goicp.cpp:1689-1697) into sh.fpv[].
@@ -955,22 +993,26 @@ __device__ __forceinline__ void heap_pop_wave(const HeapStoreT<N>& a, int& n, in
         const int len = n - 1;
         const N v = a.get(len);
         const N top = a.get(0);
-        if (lane == 0) a.set(len, top);
-        int hole = 0, child = 0;
+        // the walk down only READS (the next level's children do not depend on this level's move); lane k remembers the node that
+        // moves up at level k and all moves are stored together afterwards -- one LDS round trip per level instead of a read-write pair
+        N mine = v; int mine_to = -1;
+        int hole = 0, child = 0, lvl = 0;
         while (child < (len - 1) / 2) {
             child = 2 * (child + 1);
             const N c1 = a.get(child), c0 = a.get(child - 1);
             const bool left = key_lower(c1.lb, c1.w, c0.lb, c0.w);
             if (left) child--;
-            if (lane == 0) a.set(hole, left ? c0 : c1);
-            hole = child;
+            if (lane == lvl) { mine = left ? c0 : c1; mine_to = hole; }
+            hole = child; lvl++;
         }
         if ((len & 1) == 0 && child == (len - 2) / 2) {
             child = 2 * (child + 1);
             const N c0 = a.get(child - 1);
-            if (lane == 0) a.set(hole, c0);
-            hole = child - 1;
+            if (lane == lvl) { mine = c0; mine_to = hole; }
+            hole = child - 1; lvl++;
         }
+        if (mine_to >= 0) a.set(mine_to, mine);
+        if (lane == 63) a.set(len, top);
         wave_sync_lds();
         heap_up_wave(a, hole, v, lane);
     }
@@ -1049,8 +1091,16 @@ __device__ __forceinline__ void sweep_stream(const DevTables& T, TileShm<BLOCK>&
             }
         }
         float v[TC];
+        if (T.code) {
+            unsigned c[TC];
 #pragma unroll
-        for (int j = 0; j < TC; j++) v[j] = T.dist[idx[j]];
+            for (int j = 0; j < TC; j++) c[j] = T.code[idx[j]];
+#pragma unroll
+            for (int j = 0; j < TC; j++) v[j] = dt_decode(T, idx[j], c[j], nullptr);
+        } else {
+#pragma unroll
+            for (int j = 0; j < TC; j++) v[j] = T.dist[idx[j]];
+        }
         if (__any((int)oob)) {
 #pragma unroll
             for (int j = 0; j < TC; j++) {
@@ -1347,20 +1397,21 @@ __global__ __launch_bounds__(BLOCK, (BLOCK == 256 ? 2 : (JIT ? 4 : 1))) void k_i
 #define STAMP(k) do { if (timing) { const unsigned long long now_ = clock64(); tph[k] += now_ - tlast; tlast = now_; } } while (0)
 
     for (;;) {
-        if (tid == 0) {
+        if (tid < 64) {
+            // wave 0, uniform control flow (every lane carries the same search state): pop with the wave-wide walk of heap_pop_wave
             int done = 0;
             if (hn == 0) done = 1;
             else {
-                parent = heap.get(0);
-                heap_pop(heap, hn);
+                const HeapNode par = heap.get(0);
+                heap_pop_wave(heap, hn, tid);
                 pops++;
-                if (optErrorT - parent.lb < job.SSEThresh) done = 1;          // reference jly_goicp.cpp:317
+                if (optErrorT - par.lb < job.SSEThresh) done = 1;             // reference jly_goicp.cpp:317
                 else if (pops > (job.max_pops ? job.max_pops : max_pops)) { done = 1; status = GOICP_ERR_LIMIT; }
                 else if (hn + 8 > heap_cap) { done = 1; status = GOICP_ERR_OVERFLOW; }
+                if (tid == 0) parent = par;
             }
-            sh.ctl[0] = done;
+            if (tid == 0) sh.ctl[0] = done;
         }
-        if (tid < 64) hn = __shfl(hn, 0, 64);                    // the pop above ran on lane 0 only
         STAMP(0);
         __syncthreads();
         if (sh.ctl[0]) break;
@@ -1665,8 +1716,9 @@ __global__ __launch_bounds__(FR_SELECT_THREADS) void k_fr_select(FrCtx C, int ro
 //         NT = 8 / ngroups children of the node (two items of 4 children each keep the residuals within 128 registers at 2 workgroups per CU)
 // MODE 1: streamed cloud (sweep_stream, trimmed or untrimmed)          MODE 2: streamed untrimmed cloud, one slice of the points per item
 template <int BLOCK, int PPT, int MODE, int NT>
-__device__ __forceinline__ void fr_expand_item(const DevTables& T, const FrCtx& C, TileShm<BLOCK>& sh, const FrItem item, float* rows) {
+__device__ __forceinline__ void fr_expand_item(const DevTables& T, const FrCtx& C, TileShm<BLOCK>& sh, const FrItem item, float* rows, float* lutl) {
     const int tid = threadIdx.x;
+    if (MODE == 0 && T.code) { for (int i = tid; i < LUT_LDS; i += BLOCK) lutl[i] = T.lut[i]; }   // (ordered by the barrier behind the cube set-up)
     const int level = C.jobs[item.job].rot_level;
     const float4* rot = C.srot + (size_t)item.job * C.NdP;
     const float* rho = level >= 0 ? T.maxRotDis + (size_t)level * T.Nd : nullptr;
@@ -1685,7 +1737,7 @@ __device__ __forceinline__ void fr_expand_item(const DevTables& T, const FrCtx& 
         float px[PPT], py[PPT], pz[PPT], pw[PPT], prho[PPT];
 #pragma unroll
         for (int m = 0; m < PPT; m++) { px[m] = py[m] = pz[m] = pw[m] = prho[m] = 0.f; }
-        sweep_tile<BLOCK, PPT, true, NT, true>(T, sh, px, py, pz, pw, prho, level >= 0, nullptr, false, rot, rho);
+        sweep_tile<BLOCK, PPT, true, NT, true>(T, sh, px, py, pz, pw, prho, level >= 0, nullptr, false, rot, rho, T.code ? lutl : nullptr);
         if (tid < NT) { out->ub[j0 + tid] = sh.ub[tid]; out->lb[j0 + tid] = sh.lb[tid]; }
         if (tid == 0 && item.split == 0) out->child_base = item.pad;
     } else if constexpr (MODE == 1) {
@@ -1704,18 +1756,19 @@ __device__ __forceinline__ void fr_expand_item(const DevTables& T, const FrCtx& 
 template <int BLOCK, int PPT, int MODE, int NT>
 __global__ __launch_bounds__(BLOCK, (MODE == 0 ? 4 : (BLOCK == 512 ? 4 : 1))) void k_fr_expand(DevTables T, FrCtx C, int round) {
     __shared__ TileShm<BLOCK> sh;
+    __shared__ float lutl[MODE == 0 ? LUT_LDS : 1];
     const unsigned n = min(C.wl_count[round], (unsigned)C.wl_cap);
     if constexpr (MODE == 1) {
         // a residual-row scratch per resident workgroup: persistent workgroups walk the list
         float* rows = T.srows ? T.srows + (size_t)blockIdx.x * TC * T.NdP : nullptr;
         for (unsigned it = blockIdx.x; it < n; it += gridDim.x) {
-            fr_expand_item<BLOCK, PPT, MODE, NT>(T, C, sh, C.wl[it], rows);
+            fr_expand_item<BLOCK, PPT, MODE, NT>(T, C, sh, C.wl[it], rows, lutl);
             __syncthreads();
         }
     } else {
         // one item per workgroup (the host sizes the grid from the number of live searches). Inside a loop the compiler hoists the
         // per-lane point addresses of all PPT fetches out of it and the residuals no longer fit the 128 registers of 2 workgroups per CU.
-        if (blockIdx.x < n) fr_expand_item<BLOCK, PPT, MODE, NT>(T, C, sh, C.wl[blockIdx.x], nullptr);
+        if (blockIdx.x < n) fr_expand_item<BLOCK, PPT, MODE, NT>(T, C, sh, C.wl[blockIdx.x], nullptr, lutl);
     }
 }
 
@@ -1761,15 +1814,17 @@ __global__ __launch_bounds__(BLOCK, (BLOCK == 512 ? 4 : 1)) void k_eval_cubes_st
 // k_eval_cubes: 8 free cubes per workgroup; cloud = rotation slot prepared by k_rotate
 // ---------------------------------------------------------------------------------------------
 template <int BLOCK, int PPT, int NT, bool JIT = false>
-__global__ __launch_bounds__(BLOCK, (JIT ? 4 : 1)) void k_eval_cubes(DevTables T, const float4* __restrict__ rot_all /*[slots][Nd] x,y,z,weight*/, int slot0, int level0,
+__global__ __launch_bounds__(BLOCK, (JIT ? (NT == 8 ? 4 : (NT == 4 ? 6 : 8)) : 1)) void k_eval_cubes(DevTables T, const float4* __restrict__ rot_all /*[slots][Nd] x,y,z,weight*/, int slot0, int level0,
                                                        const int2* __restrict__ groups /* (slot, rot_level) per blockIdx.y, or null */,
                                                        const float* __restrict__ cubes, int n, float* __restrict__ ub_out, float* __restrict__ lb_out,
                                                        float* fpscratch) {
     __shared__ TileShm<BLOCK> sh;
+    __shared__ float lutl[JIT ? LUT_LDS : 1];           // leading entries of the coded grid's value table (just-in-time form only)
     extern __shared__ float rbuf[];
     const int tid = threadIdx.x;
     const int Nd = T.Nd;
     const int base = blockIdx.x * NT;
+    if (JIT && T.code) { for (int i = tid; i < LUT_LDS; i += BLOCK) lutl[i] = T.lut[i]; }      // (ordered by the barrier behind the cube set-up)
     // one launch can sweep the same cube list for many (rotation, rho-level) pairs: blockIdx.y picks the pair
     int slot = slot0, rot_level = level0;
     if (groups) { const int2 g = groups[blockIdx.y]; slot = g.x; rot_level = g.y; }
@@ -1797,8 +1852,21 @@ __global__ __launch_bounds__(BLOCK, (JIT ? 4 : 1)) void k_eval_cubes(DevTables T
         sh.cen[j][0] = x + w / 2; sh.cen[j][1] = y + w / 2; sh.cen[j][2] = z + w / 2;
         sh.mtd[j] = (float)(SQRT3_D / 2.0 * w);
     }
+    // Phase stagger (speed only, never correctness). A tile alternates a gather phase that keeps the CU's vector-memory path busy
+    // with a selection phase that does not use it. Two workgroups that start on a CU together stay in lockstep (both gather at half
+    // rate, then both select while the memory path idles), and the pair that replaces them inherits the same phase. So the SECOND
+    // workgroup to arrive on each CU in a launch waits about half a tile once; every later workgroup of the CU starts when its
+    // predecessor ends and the offset carries through the whole launch.
+    if (JIT && T.cu_tickets) {
+        if (tid == 64) {
+            const unsigned hw = __builtin_amdgcn_s_getreg((31 << 11) | 4), xcc = __builtin_amdgcn_s_getreg((31 << 11) | 20);   // HW_REG_HW_ID, HW_REG_XCC_ID
+            const unsigned cu = ((xcc & 7u) << 8) | ((hw >> 8) & 0xffu);                                                       // CU_ID, SH_ID, SE_ID of this XCD
+            sh.ctl[3] = atomicAdd(&T.cu_tickets[cu], 1u) == 1u ? 1 : 0;
+        }
+    }
     const bool penalties = T.use_compat || T.use_fpfh;
     __syncthreads();
+    if (JIT && T.cu_tickets && sh.ctl[3]) { for (int q = 0; q < T.stagger_sleeps; q++) __builtin_amdgcn_s_sleep(127); }
     // every lane decides for itself whether the tile is a row of x-neighbours (broadcast LDS reads, no second barrier)
     bool row = true;
 #pragma unroll
@@ -1809,7 +1877,7 @@ __global__ __launch_bounds__(BLOCK, (JIT ? 4 : 1)) void k_eval_cubes(DevTables T
         sh.lat[tid][1] = sh.cube[j][1] + (c >> 1 & 1) * sh.cube[j][3];
         sh.lat[tid][2] = sh.cube[j][2] + (c >> 2 & 1) * sh.cube[j][3];
     }
-    sweep_tile<BLOCK, PPT, false, NT, JIT>(T, sh, px, py, pz, pw, prho, use_rho, rbuf, row, rot, rho_row_jit);
+    sweep_tile<BLOCK, PPT, false, NT, JIT>(T, sh, px, py, pz, pw, prho, use_rho, rbuf, row, rot, rho_row_jit, (JIT && T.code) ? lutl : nullptr);
     if (penalties) lattice_terms<BLOCK, PPT>(T, sh, 8 * NT, px, py, pz, fpbuf);
     if (tid < NT && base + tid < n) {
         const int j = tid;
@@ -1826,6 +1894,42 @@ __global__ __launch_bounds__(BLOCK, (JIT ? 4 : 1)) void k_eval_cubes(DevTables T
         }
         ub_out[base + j] = ub; lb_out[base + j] = lb;
     }
+}
+
+// Diagnosis only (goicp_engine_debug_gather_probe): the DT gathers of k_eval_cubes' row tiles -- same grid, same rotated clouds, same
+// cube list, same (double) cell arithmetic, 8 lookups per point in flight -- with nothing else: no residuals kept, no selection.
+// Its run time is the memory-system floor of the metric kernel's ACTUAL access pattern (unlike tools/probes/gather_probe.hip,
+// whose synthetic tiles repeat and stay L2-resident).
+template <int BLOCK, int PPT>
+__global__ __launch_bounds__(BLOCK) void k_gather_probe(DevTables T, const float4* __restrict__ rot_all, const int2* __restrict__ groups,
+                                                        const float* __restrict__ cubes, int n, float* __restrict__ out) {
+    __shared__ float cen[TC][3];
+    const int tid = threadIdx.x, Nd = T.Nd, S = T.S;
+    const int base = blockIdx.x * TC;
+    const int2 g = groups[blockIdx.y];
+    const float4* __restrict__ rot = rot_all + (size_t)g.x * Nd;
+    if (tid < TC) {
+        const int c = min(base + tid, n - 1);
+        const float w = cubes[4 * c + 3];
+        cen[tid][0] = cubes[4 * c] + w / 2; cen[tid][1] = cubes[4 * c + 1] + w / 2; cen[tid][2] = cubes[4 * c + 2] + w / 2;
+    }
+    __syncthreads();
+    float acc = 0.f;
+#pragma unroll
+    for (int m = 0; m < PPT; m++) {
+        const float4 p = rot[min(tid + m * BLOCK, Nd - 1)];
+        const int y = cell_of(p.y + cen[0][1], T.yMin, T.scale), z = cell_of(p.z + cen[0][2], T.zMin, T.scale);
+        const int rowbase = (clamp_cell(z, S) * S + clamp_cell(y, S)) * S;
+        float v[TC];
+#pragma unroll
+        for (int j = 0; j < TC; j++) {
+            const unsigned ix = (unsigned)(rowbase + clamp_cell(cell_of(p.x + cen[j][0], T.xMin, T.scale), S));
+            v[j] = T.code ? (float)T.code[ix] : T.dist[ix];
+        }
+#pragma unroll
+        for (int j = 0; j < TC; j++) acc += v[j];
+    }
+    if (acc == 12345.678f) out[blockIdx.x] = acc;
 }
 
 // lattice terms only, at n free translations (NLMAX per workgroup)
@@ -1862,6 +1966,24 @@ __global__ void k_build_cmask(const int* __restrict__ nearest, const int* __rest
     const int o = (nk >= 0 && (unsigned long long)nk < ncell) ? occ_id[nk] : -1;
     cmask[k] = o < 0 ? (uint16_t)0 : occ_mask[o];
     if (occ_out) occ_out[k] = o;
+}
+
+// coded grid: d2 = round((dist * scale)^2) is accepted as the cell's code only if the LUT gives back the cell's float bit for bit
+__global__ void k_build_codes(const float* __restrict__ dist, const float* __restrict__ lut, int lut_n, double scale, unsigned long long ncell,
+                              uint16_t* __restrict__ code, unsigned long long* __restrict__ escapes) {
+    const unsigned long long k = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
+    bool esc = false;
+    if (k < ncell) {
+        const float d = dist[k];
+        const double t = (double)d * scale;
+        const double n = rint(t * t);
+        unsigned c = 0xFFFFu;
+        if (n >= 0.0 && n < (double)lut_n && n < 65535.0) { const unsigned ni = (unsigned)n; if (__float_as_uint(lut[ni]) == __float_as_uint(d)) c = ni; }
+        code[k] = (uint16_t)c;
+        esc = c == 0xFFFFu;
+    }
+    const unsigned long long b = __ballot(esc);
+    if ((threadIdx.x & 63) == 0 && b) atomicAdd(escapes, (unsigned long long)__popcll(b));
 }
 
 // K5: rotated cloud + weight as float4 (reference jly_goicp.cpp:750-756)
@@ -1948,6 +2070,8 @@ struct goicp_engine {
     int block, ppt; size_t dyn_lds; size_t dyn_lds_bnb; int heap_lds_nodes; int rbuf_floats; int fp_lds;
     int resident_jobs;                       // search workgroups resident at once (CUs x occupancy of the chosen k_inner_bnb)
     int streamed; size_t stream_wgs, stream_rot_wgs;   // streaming path: scratch sized for this many resident workgroups (rows / rotated clouds)
+    int stagger;                             // phase stagger of the two workgroups of a CU (k_eval_cubes, just-in-time form): sleep repetitions, 0 = off
+    int eval_nt;                             // cubes per workgroup tile of the just-in-time sweep kernel (experiment knob GOICP_EVAL_NT: 8, 4 or 2)
     int jit_bnb;                             // geometric searches of 1025..2048 points: k_inner_bnb<512, 4, false, false, true>
     // round-based search (k_fr_*): geometric searches of more than 1024 points
     int fr_mode;                             // 0 off, else 1 + MODE of k_fr_expand
@@ -1958,6 +2082,7 @@ struct goicp_engine {
     unsigned max_pops;
     uint64_t n_cubes, n_lookups; double kernel_ms;
     std::string err, kernel_name;
+    unsigned long long code_escapes;          // cells of the coded grid that fall back to the float grid
 };
 
 // ---------------------------------------------------------------------------------------------
@@ -2159,6 +2284,9 @@ extern "C" int goicp_engine_create(const goicp_engine_desc* d, goicp_engine** ou
     h->streamed = 0; h->stream_wgs = 0; h->stream_rot_wgs = 0; h->pinned = nullptr;
     h->d_heaps = nullptr; h->d_fpscratch = nullptr; h->heap_cap = 8192; h->heap_jobs = 0; h->fp_blocks = 0; h->d_heap_big = nullptr; h->heap_big_cap = 0;
     h->n_cubes = h->n_lookups = 0; h->kernel_ms = 0; h->max_pops = 200000000u;
+    { const char* e = getenv("GOICP_EVAL_NT"); h->eval_nt = (e && (atoi(e) == 4 || atoi(e) == 2)) ? atoi(e) : 8; }
+    { const char* e = getenv("GOICP_STAGGER"); h->stagger = e ? atoi(e) : 5; }      // s_sleep(127) repetitions; 0 switches the stagger off
+    h->code_escapes = 0;
     h->fr_mode = 0; h->fr_st = nullptr; h->fr_heaps = nullptr; h->fr_exps = nullptr; h->fr_wl = nullptr; h->fr_cnt = nullptr; h->fr_parts = nullptr; h->fr_srot = nullptr; h->fr_results = nullptr;
     h->fr_jobs = 0; h->fr_cap_nodes = 0; h->fr_cap_exps = 0; h->fr_wl_cap = 0; h->fr_rounds = 0; h->fr_spec_cubes = 0;
 #define CR(call) do { int rc_ = (call); if (rc_ != GOICP_OK) { std::string m = h->err; goicp_engine_destroy(h); fprintf(stderr, "goicp_engine_create: %s\n", m.c_str()); return rc_; } } while (0)
@@ -2180,6 +2308,27 @@ extern "C" int goicp_engine_create(const goicp_engine_desc* d, goicp_engine** ou
     const size_t ncell = (size_t)d->S * d->S * d->S;
     if (sparse) T.dist = (const float*)d->dt_dist_dev;        // adopted in place (owned by the caller's goicp_dtgpu handle)
     else { float* p_dist; CR(dev_upload(h, d->dt_dist, ncell, &p_dist)); T.dist = p_dist; }
+    T.code = nullptr; T.lut = nullptr;
+    {   // 2-byte coded copy of the grid for the gather stream (grids of 100^3 cells and more; GOICP_CODED=0 switches it off)
+        const char* e = getenv("GOICP_CODED");
+        if (d->S >= 100 && !(e && atoi(e) == 0)) {
+            const long long full = 3ll * (d->S - 1) * (d->S - 1) + 1;
+            const int lut_n = (int)std::min<long long>(full, 65535);
+            std::vector<float> lut((size_t)std::max(lut_n, LUT_LDS), 0.f);
+            for (int n = 0; n < lut_n; n++) lut[(size_t)n] = (float)((double)(float)sqrt((double)n) / d->scale);     // jly_3ddt.cpp:28,79,1003
+            float* p_lut; CR(dev_upload(h, lut.data(), lut.size(), &p_lut));
+            uint16_t* p_code; CR(dev_upload<uint16_t>(h, nullptr, ncell, &p_code));
+            unsigned long long* p_esc; CR(dev_upload<unsigned long long>(h, nullptr, 1, &p_esc));
+            CRH(hipMemsetAsync(p_esc, 0, sizeof(unsigned long long), h->stream));
+            hipLaunchKernelGGL(k_build_codes, dim3((unsigned)((ncell + 255) / 256)), dim3(256), 0, h->stream, T.dist, p_lut, lut_n, d->scale, (unsigned long long)ncell, p_code, p_esc);
+            CRH(hipGetLastError());
+            unsigned long long esc = 0;
+            CRH(hipMemcpyAsync(&esc, p_esc, sizeof esc, hipMemcpyDeviceToHost, h->stream));
+            CRH(hipStreamSynchronize(h->stream));
+            h->code_escapes = esc;
+            if ((double)esc <= 0.25 * (double)ncell) { T.code = p_code; T.lut = p_lut; }      // mostly escapes: the float grid alone is the better stream
+        }
+    }
     float* p_dxyz; CR(dev_upload(h, d->data_xyz, (size_t)3 * d->Nd, &p_dxyz)); T.dxyz = p_dxyz;
     float* p_w; CR(dev_upload(h, d->weights, (size_t)d->Nd, &p_w)); T.weights = p_w;
     float* p_mrd; CR(dev_upload(h, d->maxRotDis, (size_t)GOICP_MAXROTLEVEL * d->Nd, &p_mrd)); T.maxRotDis = p_mrd;
@@ -2277,6 +2426,8 @@ extern "C" int goicp_engine_create(const goicp_engine_desc* d, goicp_engine** ou
     CR(dev_upload<int>(h, nullptr, h->lat_cap, &h->d_cnt));
     CR(dev_upload<float>(h, nullptr, h->lat_cap, &h->d_fp));
     { unsigned long long* p_t; CR(dev_upload<unsigned long long>(h, nullptr, 16, &p_t)); CRH(hipMemset(p_t, 0, 128)); T.dbg_times = p_t; }
+    T.cu_tickets = nullptr; T.stagger_sleeps = h->stagger;
+    if (h->stagger > 0) { unsigned* p_t; CR(dev_upload<unsigned>(h, nullptr, 8 * 256, &p_t)); T.cu_tickets = p_t; }
     pick_geometry(h);
     if (h->dyn_lds_bnb + sizeof(TileShm<1024>) + 64 > 160 * 1024) { h->err = "LDS budget exceeded"; CR(GOICP_ERR_ARG); }
     {
@@ -2304,7 +2455,7 @@ extern "C" int goicp_engine_create(const goicp_engine_desc* d, goicp_engine** ou
             h->resident_jobs = std::max(1, nb) * std::max(1, ncu);
             // searches of more than 1024 points without penalty terms run round by round over many workgroups (k_fr_*)
             h->fr_mode = 0; h->fr_nsplit = 1; h->fr_ppt = 4; h->fr_block = 512; h->fr_wgs = 2 * std::max(1, ncu); h->fr_heap_cap = 8192;
-            h->fr_depth2 = !(getenv("GOICP_FR_DEPTH") && atoi(getenv("GOICP_FR_DEPTH")) == 1);      // A/B knob, read once per engine
+            h->fr_depth2 = (getenv("GOICP_FR_DEPTH") && atoi(getenv("GOICP_FR_DEPTH")) == 2) ? 1 : 0;   // two-level expansion: measured slower on configs[2] (more sweeps per round than rounds saved); knob kept for deep searches
             const bool fr_off = getenv("GOICP_FR") && atoi(getenv("GOICP_FR")) == 0;          // A/B knob, read once per engine
             if (!fr_off && !T.exact && !T.use_compat && !T.use_fpfh && d->Nd > 1024) {
                 if (!h->streamed) { h->fr_mode = 1; h->fr_block = 512; h->fr_ppt = d->Nd <= 2048 ? 4 : (d->Nd <= 4096 ? 8 : 10); h->fr_wgs = 2 * std::max(1, ncu); }
@@ -2412,15 +2563,36 @@ static int launch_eval(goicp_engine* h, int slot, int rot_level, const int2* gro
     // clouds of 1025..5120 points without penalty terms: 512 lanes x twice the points, the points fetched just in time instead of
     // held in registers -> 128 VGPRs, two workgroups per CU, one gathering while the other selects (3.89 -> 3.52 ms at C3)
     const bool jit = h->block == 1024 && h->ppt >= 2 && !h->T.exact && !h->T.use_compat && !h->T.use_fpfh && !(getenv("GOICP_JIT") && atoi(getenv("GOICP_JIT")) == 0);
+    if (jit && h->T.cu_tickets) HIPCHK(h, hipMemsetAsync(h->T.cu_tickets, 0, 8 * 256 * sizeof(unsigned), h->stream));
 #define CALLJ(P2) hipLaunchKernelGGL((k_eval_cubes<512, P2, TC, true>), dim3(tiles, ngroups), dim3(512), h->dyn_lds, h->stream, h->T, h->d_rot, slot, rot_level, groups_dev, (const float*)cubes_dev, n, (float*)ub_dev, (float*)lb_dev, h->d_fpscratch)
+#define CALLJN(P2, NTT) hipLaunchKernelGGL((k_eval_cubes<512, P2, NTT, true>), dim3((n + NTT - 1) / NTT, ngroups), dim3(512), h->dyn_lds, h->stream, h->T, h->d_rot, slot, rot_level, groups_dev, (const float*)cubes_dev, n, (float*)ub_dev, (float*)lb_dev, h->d_fpscratch)
     if (jit && h->ppt == 2) CALLJ(4);
     else if (jit && h->ppt == 4) CALLJ(8);
+    else if (jit && h->ppt == 5 && h->eval_nt == 4) CALLJN(10, 4);
+    else if (jit && h->ppt == 5 && h->eval_nt == 2) CALLJN(10, 2);
     else if (jit && h->ppt == 5) CALLJ(10);
     else DISPATCH_GEOM(h, CALL);
+#undef CALLJN
 #undef CALLJ
 #undef CALL
     HIPCHK(h, hipGetLastError());
     h->n_cubes += (uint64_t)n * ngroups; h->n_lookups += (uint64_t)n * ngroups * h->T.Nd;
+    return GOICP_OK;
+}
+
+extern "C" int goicp_engine_debug_gather_probe(goicp_engine* h, const void* cubes_dev, int n, void* scratch_dev, int variant, float* ms_out) {
+    // diagnosis: the gathers of one goicp_engine_eval_cubes_multi_dev launch (the group table of the last such call) and nothing else
+    if (!h || !cubes_dev || !scratch_dev || n <= 0 || h->groups_host.empty()) return GOICP_ERR_ARG;
+    HIPCHK(h, hipSetDevice(h->device));
+    const int tiles = (n + TC - 1) / TC, ngroups = (int)h->groups_host.size();
+    HIPCHK(h, hipEventRecord(h->ev0, h->stream));
+    if (variant == 0) hipLaunchKernelGGL((k_gather_probe<512, 10>), dim3(tiles, ngroups), dim3(512), 0, h->stream, h->T, h->d_rot, h->d_groups, (const float*)cubes_dev, n, (float*)scratch_dev);
+    else hipLaunchKernelGGL((k_gather_probe<1024, 5>), dim3(tiles, ngroups), dim3(1024), 0, h->stream, h->T, h->d_rot, h->d_groups, (const float*)cubes_dev, n, (float*)scratch_dev);
+    HIPCHK(h, hipGetLastError());
+    HIPCHK(h, hipEventRecord(h->ev1, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    float ms = 0.f; (void)hipEventElapsedTime(&ms, h->ev0, h->ev1);
+    if (ms_out) *ms_out = ms;
     return GOICP_OK;
 }
 
@@ -2616,7 +2788,8 @@ static int run_fr(goicp_engine* h, const goicp_bnb_job* jobs, int njobs, goicp_b
     for (int batch = 0; active > 0; batch++) {
         // few live searches: every chosen node is expanded two levels deep (9 tiles) and up to FR_KMAX nodes are chosen per search;
         // many live searches: one level, as many nodes as still fit the target
-        int depth = ((long long)active * 9 * per_tile <= target && h->fr_depth2) ? 2 : 1;
+        // (measured on the 16 searches of a configs[2] rotation pop: one level 9.3 ms / 184 rounds, two levels 11.9 ms / 120 rounds)
+        int depth = ((long long)active * 9 * per_tile * 8 <= target && h->fr_depth2) ? 2 : 1;
         const int slots = depth == 2 ? 9 : 1;
         const int K = std::max(1, std::min(FR_KMAX, target / (int)std::max(1ll, (long long)active * slots * per_tile)));
         HIPCHK(h, hipMemsetAsync(h->fr_cnt, 0, 2 * FR_ROUNDS_MAX * sizeof(unsigned), h->stream));

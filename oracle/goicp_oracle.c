@@ -91,6 +91,7 @@ struct orc_ctx {
     int* opt_pts;                    /* those of the last accepted run (icp3d.optPoints) */
     /* instrumentation */
     long long n_tpop, n_rpop, n_cube, n_corner;
+    long long pop_budget;            /* 0: none; else InnerBnB stops after this many queue pops (orc_set_pop_budget) */
     float* trace; long long trace_n, trace_cap; int trace_on;
     char* log; size_t log_n, log_cap;
 };
@@ -648,13 +649,15 @@ void orc_eval_cube(orc_ctx* c, int level, float nx, float ny, float nz, float nw
 static float inner_bnb(orc_ctx* c, int level, tnode* out) {
     theap q = {0, 0, 0};
     float optErrorT = c->optError;
+    long long pops = 0;
     theap_push(&q, c->initTrans);
     if (c->trace_on && c->trace_n < c->trace_cap) { memcpy(c->trace + 6 * c->trace_n, &c->initTrans, sizeof(tnode)); c->trace_n++; }
     for (;;) {
         if (q.n == 0) break;
         tnode par = q.a[0];
-        theap_pop(&q); c->n_tpop++;
+        theap_pop(&q); c->n_tpop++; pops++;
         if (optErrorT - par.lb < c->SSEThresh) break;
+        if (c->pop_budget > 0 && pops > c->pop_budget) break;      /* test hook: bounded prefix of a deep search */
         tnode ch; ch.w = par.w / 2;
         for (int j = 0; j < 8; j++) {
             ch.x = par.x + (j & 1) * ch.w; ch.y = par.y + (j >> 1 & 1) * ch.w; ch.z = par.z + (j >> 2 & 1) * ch.w;
@@ -670,6 +673,8 @@ static float inner_bnb(orc_ctx* c, int level, tnode* out) {
     free(q.a);
     return optErrorT;
 }
+
+void orc_set_pop_budget(orc_ctx* c, long long n) { c->pop_budget = n; }
 
 float orc_inner_bnb(orc_ctx* c, int level, float* node_out, int want_node) {
     tnode n; memset(&n, 0, sizeof n);

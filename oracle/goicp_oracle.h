@@ -54,6 +54,7 @@ void  orc_rotate(orc_ctx*, const float* R9);    /* pDataTemp = R*pData, jly_goic
 /* one translation cube -> (ub, lb) incl. corner penalty terms, jly_goicp.cpp:322-550; level<0: no rho */
 void  orc_eval_cube(orc_ctx*, int level, float x, float y, float z, float w, float* ub, float* lb);
 float orc_inner_bnb(orc_ctx*, int level, float* node_out6, int want_node);   /* jly_goicp.cpp:286-579 */
+void orc_set_pop_budget(orc_ctx*, long long n);   /* test hook: InnerBnB returns after n queue pops (0 = unbounded), like a job's max_pops on the device */
 int   orc_check_compatibilities(orc_ctx*, float x, float y, float z);        /* jly_goicp.cpp:919-928 */
 float orc_sum_fpfh(orc_ctx*, float x, float y, float z);                     /* jly_goicp.cpp:1689-1697 */
 float orc_icp(orc_ctx*, double* R9, double* t3, int* corr, double* dis);     /* jly_goicp.cpp:102-178 */

@@ -424,6 +424,9 @@ class Oracle:
             out[i] = self.eval_cube(level, *cb)
         return out[:, 0].copy(), out[:, 1].copy()
 
+    def set_pop_budget(self, n):
+        self.lib.orc_set_pop_budget(self.h, C.c_longlong(int(n)))
+
     def inner_bnb(self, level, want_node=True):
         node = np.zeros(6, np.float32)
         r = self.lib.orc_inner_bnb(self.h, int(level), _p(node, C.c_float), 1 if want_node else 0)

@@ -437,6 +437,39 @@ def test_full_size_properties(n, S, trim):
     g.close()
 
 
+@pytest.mark.parametrize("n,S,trim,mse", [(50000, 500, 0.0, 1e-5), (5000, 300, 0.1, 1e-3)])
+def test_bounded_search_prefix_against_the_oracle(n, S, trim, mse):
+    """BASELINE configs[4] (50 000 points, 500^3 grid, MSEThresh 1e-5: a deep search nobody runs to the end on one CPU core) and
+    configs[2]: the first 250 queue pops = 2 000 cube evaluations of searches from the root, on the device
+    (job.max_pops) and in the oracle (pop budget) on the same grid: same best node, upper bound within max(1e-5, n*2^-24)
+    relative, same number of pops -- for a ub-call and an lb-call, under three rotations."""
+    P = synth_pair(n)
+    v, _ = cfg_vector(distTransSize=S, trimFraction=trim, regularization=0.0, ponderation=0, MSEThresh=mse)
+    g = goicp_amd.GoICP(v); g.set_clouds(P["t"], P["s"]); g.build_dt(); g.initialize()
+    e = g.engine()
+    dist, _, _ = g.dt_dump()
+    from oracle.refbind import Oracle
+    o = Oracle(); o.set_config(v); o.set_clouds(P["t"], P["s"]); o.load_dt(S, g.geom, dist); o.initialize()
+    o.set_pop_budget(250)
+    rng = np.random.default_rng(n)
+    sse = np.float32(g.sse_thresh())
+    jobs = []
+    for k in range(3):
+        R = o.axis_angle(rng.uniform(-1.5, 1.5, 3).astype(np.float32))
+        for lvl in (-1, 2):
+            jobs.append(dict(R=R, level=lvl, E=float(n) * 0.5, sse=float(sse), init=(-0.5, -0.5, -0.5, 1.0), max_pops=250))
+    got = e.inner_bnb_batch(jobs)
+    rtol = max(1e-5, n * 2.0 ** -24)
+    for j, r in zip(jobs, got):
+        o.rotate(j["R"]); o.set_opt_error(np.float32(j["E"])); o.counters(reset=True)
+        val, node = o.inner_bnb(j["level"])
+        pops = o.counters(reset=True)[0]
+        assert r["status"] in (0, 5) and r["pops"] == pops, (r["pops"], pops)
+        assert abs(float(r["val"]) - float(val)) <= rtol * abs(float(val)), (r["val"], val)
+        assert r["found"] and np.array_equal(r["node"], np.asarray(node[:4], np.float32))
+    g.close()
+
+
 def _default_config_file(path, **over):
     d = dict(goicp_amd.DEFAULT_CFG); d.update(over)
     with open(path, "w") as f:

@@ -33,6 +33,10 @@ for k, cs in out["pmc"].items():
         fetch = cs["FETCH_SIZE"]["avg"] * 1024.0
         write = cs.get("WRITE_SIZE", {"avg": 0})["avg"] * 1024.0
         out["hbm_bytes_per_launch"] = fetch + write
+        out["kernel"] = k.replace("void ", "").replace(", ", ",")
+        hit = cs.get("TCC_HIT_sum", {}).get("avg"); miss = cs.get("TCC_MISS_sum", {}).get("avg")
+        if hit is not None and miss is not None and hit + miss > 0:
+            out["l2_hit_rate"] = hit / (hit + miss)
         out["fetch_note"] = ("FETCH_SIZE*1024 (+WRITE_SIZE*1024). The accesses are 4-byte gathers, i.e. 64-B requests, so the guide's x2 "
                              "correction for wide 128-B streaming reads does not apply; the 108 MB grid is Infinity-Cache resident, so this is "
                              "fabric-side traffic, an upper bound of HBM-device traffic.")
