@@ -69,7 +69,7 @@ def parse_args():
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--cpu-workers", type=int, default=0, help="all-cores CPU baseline: worker processes (0 = min(host cpus, 32))")
     ap.add_argument("--cavity-rows", type=int, default=383, help="rows of the configs[3] batch (whole job, sharded over the ranks)")
-    ap.add_argument("--cavity-threads", type=int, default=8, help="host threads (= concurrent registrations, one engine + stream each) per rank")
+    ap.add_argument("--cavity-threads", type=int, default=16, help="host threads (= concurrent registrations, one engine + stream each) per rank")
     ap.add_argument("--overlap-pairs", type=int, default=4, help="configs[2]-shaped pairs registered with their DT builds overlapped on host threads")
     return ap.parse_args()
 
@@ -178,6 +178,25 @@ def main():
     checksum = float(ub.double().sum().item() + lb.double().sum().item())
     assert np.isfinite(checksum)
     kname = eng.eval_kernel_name()
+    # The launch group holds every rotation twice (rho = 0 and rho = maxRotDis[3], as OuterBnB's ub / lb calls do), and the engine
+    # evaluates such pairs from ONE pass of gathers (k_eval_cubes_geo<.., true>). For transparency the same launch group is also timed
+    # with the fusion switched off (a second engine on the same grid): reported beside the line, never as `value`.
+    unfused = None
+    if kname.endswith("true>") and rank == 0:
+        os.environ["GOICP_FUSE"] = "0"
+        try:
+            g.initialize(); eng_u = g.engine()
+            for s_, R in enumerate(rots):
+                eng_u.set_rotation(s_, R)
+            eng_u.eval_cubes_multi_dev(g_slots, g_levels, cubes.data_ptr(), ncube, ub.data_ptr(), lb.data_ptr()); eng_u.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(20):
+                eng_u.eval_cubes_multi_dev(g_slots, g_levels, cubes.data_ptr(), ncube, ub.data_ptr(), lb.data_ptr())
+            eng_u.synchronize()
+            unfused = dict(kernel=eng_u.eval_kernel_name(), avg_launch_ms=(time.perf_counter() - t0) / 20 * 1e3)
+            unfused["frac"] = bytes_per_launch / (unfused["avg_launch_ms"] * 1e-3) / 1e9 / PEAK_HBM_GBPS
+        finally:
+            del os.environ["GOICP_FUSE"]
 
     # ---- end-to-end registration of the same pair ------------------------------------------------------
     reg = None
@@ -237,8 +256,8 @@ def main():
         if default_shape and os.path.exists(pj):     # the committed PMC summary belongs to the default shape only
             try:
                 S = json.load(open(pj))
-                if S.get("kernel") == kname:
-                    traffic = S.get("hbm_bytes_per_launch")
+                traffic = S.get("hbm_bytes_per_launch_by_kernel", {}).get(kname)
+                if traffic is not None:
                     traffic_source = "%s (separate rocprofv3 --pmc passes of this command on this build; not measured by this run)" % PMC_SUMMARY
             except Exception:
                 traffic = None
@@ -252,7 +271,8 @@ def main():
                        "points": nd, "dt_size": args.dt, "trimFraction": args.trim, "cube_evals_per_step": evals_per_step, "parallelism": "pairs sharded, 1 rank per GPU"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": PEAK_HBM_GBPS, "unit": "GB/s", "frac": achieved / PEAK_HBM_GBPS, "traffic": traffic,
                          "traffic_source": traffic_source, "kernel": kname, "avg_launch_ms": kern_ms, "algorithmic_bytes_per_launch": bytes_per_launch,
-                         "point_lookups_per_sec": value / world * nd},
+                         "point_lookups_per_sec": value / world * nd,
+                         "fused_group_pairs": kname.endswith("true>"), "unfused": unfused},
             "cpu_baseline": cpu,
             "registration": reg,
             "cavity_batch": cav,

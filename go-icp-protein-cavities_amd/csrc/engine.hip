@@ -62,8 +62,6 @@ struct DevTables {
     float4* srot;            // streaming path (Nd > 8192): per-workgroup rotated cloud [NdP]
     float* srows;            // streaming path, trimmed runs: per-workgroup residual rows [TC][NdP]
     int NdP;                 // row pitch of the two above
-    unsigned* cu_tickets;    // [8*256] per-CU arrival counters of the current k_eval_cubes launch (phase stagger), or null
-    int stagger_sleeps;      // s_sleep(127) repetitions (~8 k cycles each) the second workgroup of a CU waits before its first tile
     int dbg;                 // GOICP_DBG ablation bits (diagnosis only; results are wrong when set)
     unsigned long long* dbg_times;   // [8] per-phase cycle sums of job 0, lane 0 (GOICP_DBG & 32)
 };
@@ -305,6 +303,7 @@ struct TileShm {
     unsigned cand[TC][CAND_CAP];
     double red[BLOCK / 64][2 * TC];
     float ub[TC], lb[TC];
+    float ub2[TC], lb2[TC];   // fused form: bounds of the first of the two calls
     float lat[NLMAX][3];
     int cnt[NLMAX];
     float fpv[NLMAX];
@@ -317,12 +316,16 @@ struct TileShm {
 // NT = cubes of the tile (TC everywhere today; 4-cube tiles with two 512-lane workgroups per CU measured no faster)
 // JIT = true: the lane's points are not held in registers; point m is fetched from `jit_rot` / `jit_rho` just before its gathers
 // (one point ahead), which frees the registers a second workgroup per CU needs (512 lanes x 10 points, k_eval_cubes only).
-template <int BLOCK, int PPT, bool OCT, int NT, bool JIT = false>
+// DUAL = true (just-in-time, non-parity form): the tile is evaluated for TWO calls that share rotation and cubes -- the ub-call
+// (no rotation uncertainty) and an lb-call (radius row dual_rho) -- from ONE pass of gathers: results of the first in sh.ub2 / sh.lb2,
+// of the second in sh.ub / sh.lb. OuterBnB's two InnerBnB calls per child rotation (jly_goicp.cpp:768,861) read the same DT cells.
+template <int BLOCK, int PPT, bool OCT, int NT, bool JIT = false, bool DUAL = false>
 __device__ __forceinline__ void sweep_tile(const DevTables& T, TileShm<BLOCK>& sh, const float (&px)[PPT], const float (&py)[PPT],
                                            const float (&pz)[PPT], const float (&pw)[PPT], const float (&prho)[PPT], bool use_rho,
                                            float* rbuf /* LDS, exact mode only */, bool row_mode = false /* !OCT: the cubes share y and z */,
                                            const float4* __restrict__ jit_rot = nullptr, const float* __restrict__ jit_rho = nullptr,
-                                           const float* lut_lds = nullptr /* LDS copy of T.lut[0, LUT_LDS) or null */) {
+                                           const float* lut_lds = nullptr /* LDS copy of T.lut[0, LUT_LDS) or null */,
+                                           const float* __restrict__ dual_rho = nullptr) {
     const int tid = threadIdx.x;
     const int Nd = T.Nd;
     float r[NT][PPT];
@@ -416,6 +419,9 @@ __device__ __forceinline__ void sweep_tile(const DevTables& T, TileShm<BLOCK>& s
         if (JIT) __builtin_amdgcn_sched_barrier(0);        // keep the point fetches one ahead instead of all up front
     }
     TSTAMP(0);
+    // everything behind the gathers (selection + sums -> sh.ub / sh.lb) as one block, so that the fused form can run it twice on the same
+    // distance values: first for the call without rotation uncertainty, then again after subtracting the radius of the other call
+    auto finish = [&]() __attribute__((always_inline)) {      // (out of line the residual registers would go through scratch memory)
     if (BLOCK * PPT <= 1024 && T.exact && T.doTrim) {
         // parity mode, trimmed: residual rows to LDS, one lane per cube runs the reference's selection (same swaps, same final
         // order), then the inlier sums are taken sequentially in float over that order -- bit-exact with jly_goicp.cpp:384-415
@@ -733,6 +739,20 @@ __device__ __forceinline__ void sweep_tile(const DevTables& T, TileShm<BLOCK>& s
         }
     }
     __syncthreads();
+    };
+    finish();
+    if constexpr (DUAL) {
+        // (two call sites rather than a loop: inside a loop the compiler hoists the block's lane-constant addresses and spills the residuals)
+        if (tid < NT) { sh.ub2[tid] = sh.ub[tid]; sh.lb2[tid] = sh.lb[tid]; }        // (ordered by the barriers of the next finish())
+        // second bound of the same cubes: minDis -= maxRotDisL; clamp (reference jly_goicp.cpp:375-381) on the products weights*DT kept in r
+#pragma unroll
+        for (int m = 0; m < PPT; m++) {
+            const float rh = dual_rho[min(tid + m * BLOCK, Nd - 1)];
+#pragma unroll
+            for (int j = 0; j < NT; j++) { float d = r[j][m] - rh; if (d < 0.f) d = 0.f; r[j][m] = d; }
+        }
+        finish();
+    }
 }
 
 #undef TSTAMP
@@ -1852,21 +1872,8 @@ __global__ __launch_bounds__(BLOCK, (JIT ? (NT == 8 ? 4 : (NT == 4 ? 6 : 8)) : 1
         sh.cen[j][0] = x + w / 2; sh.cen[j][1] = y + w / 2; sh.cen[j][2] = z + w / 2;
         sh.mtd[j] = (float)(SQRT3_D / 2.0 * w);
     }
-    // Phase stagger (speed only, never correctness). A tile alternates a gather phase that keeps the CU's vector-memory path busy
-    // with a selection phase that does not use it. Two workgroups that start on a CU together stay in lockstep (both gather at half
-    // rate, then both select while the memory path idles), and the pair that replaces them inherits the same phase. So the SECOND
-    // workgroup to arrive on each CU in a launch waits about half a tile once; every later workgroup of the CU starts when its
-    // predecessor ends and the offset carries through the whole launch.
-    if (JIT && T.cu_tickets) {
-        if (tid == 64) {
-            const unsigned hw = __builtin_amdgcn_s_getreg((31 << 11) | 4), xcc = __builtin_amdgcn_s_getreg((31 << 11) | 20);   // HW_REG_HW_ID, HW_REG_XCC_ID
-            const unsigned cu = ((xcc & 7u) << 8) | ((hw >> 8) & 0xffu);                                                       // CU_ID, SH_ID, SE_ID of this XCD
-            sh.ctl[3] = atomicAdd(&T.cu_tickets[cu], 1u) == 1u ? 1 : 0;
-        }
-    }
     const bool penalties = T.use_compat || T.use_fpfh;
     __syncthreads();
-    if (JIT && T.cu_tickets && sh.ctl[3]) { for (int q = 0; q < T.stagger_sleeps; q++) __builtin_amdgcn_s_sleep(127); }
     // every lane decides for itself whether the tile is a row of x-neighbours (broadcast LDS reads, no second barrier)
     bool row = true;
 #pragma unroll
@@ -1930,6 +1937,51 @@ __global__ __launch_bounds__(BLOCK) void k_gather_probe(DevTables T, const float
         for (int j = 0; j < TC; j++) acc += v[j];
     }
     if (acc == 12345.678f) out[blockIdx.x] = acc;
+}
+
+// k_eval_cubes_geo: the cube sweep of clouds of 1025..5120 points without penalty terms (512 lanes, points fetched just in time) -- the
+// metric kernel. A kernel of its own rather than an instantiation of k_eval_cubes: without the penalty-lattice and parity-mode code next
+// to it the 80 residuals stay in registers (106 VGPRs, no spills; the general kernel spilled 26).
+// DUAL = false: groups[y] = (slot, rot_level), output row y.
+// DUAL = true : PAIRS of groups that share rotation slot and cube list -- the call without rotation uncertainty (rot_level -1) and a call
+//               with it, as OuterBnB's two InnerBnB calls per child rotation do (reference jly_goicp.cpp:768,861): one pass of gathers, two
+//               bound pairs per cube (sweep_tile<..., DUAL>). groups[y] = (slot, rot_level of the second call, output row of the first
+//               call, output row of the second).
+template <int PPT, bool DUAL>
+__global__ __launch_bounds__(512, 4) void k_eval_cubes_geo(DevTables T, const float4* __restrict__ rot_all, const int4* __restrict__ groups,
+                                                           const float* __restrict__ cubes, int n, float* __restrict__ ub_out, float* __restrict__ lb_out) {
+    __shared__ TileShm<512> sh;
+    __shared__ float lutl[LUT_LDS];
+    const int tid = threadIdx.x, Nd = T.Nd, base = blockIdx.x * TC;
+    if (T.code) { for (int i = tid; i < LUT_LDS; i += 512) lutl[i] = T.lut[i]; }     // (ordered by the barrier behind the cube set-up)
+    const int4 g = groups[blockIdx.y];
+    const float4* __restrict__ rot = rot_all + (size_t)g.x * Nd;
+    const float* __restrict__ rho = g.y >= 0 ? T.maxRotDis + (size_t)g.y * Nd : nullptr;
+    if (tid < TC) {
+        const int j = tid, c = min(base + j, n - 1);          // the tail tile re-evaluates the last cube
+        const float x = cubes[4 * c], y = cubes[4 * c + 1], z = cubes[4 * c + 2], w = cubes[4 * c + 3];
+        sh.cube[j][0] = x; sh.cube[j][1] = y; sh.cube[j][2] = z; sh.cube[j][3] = w;
+        sh.cen[j][0] = x + w / 2; sh.cen[j][1] = y + w / 2; sh.cen[j][2] = z + w / 2;
+        sh.mtd[j] = (float)(SQRT3_D / 2.0 * w);
+    }
+    __syncthreads();
+    // every lane decides for itself whether the tile is a row of x-neighbours (broadcast LDS reads, no second barrier)
+    bool row = true;
+#pragma unroll
+    for (int j = 1; j < TC; j++) row = row && sh.cen[j][1] == sh.cen[0][1] && sh.cen[j][2] == sh.cen[0][2];
+    float px[PPT], py[PPT], pz[PPT], pw[PPT], prho[PPT];
+#pragma unroll
+    for (int m = 0; m < PPT; m++) { px[m] = py[m] = pz[m] = pw[m] = prho[m] = 0.f; }
+    if constexpr (DUAL) {
+        sweep_tile<512, PPT, false, TC, true, true>(T, sh, px, py, pz, pw, prho, false, nullptr, row, rot, nullptr, T.code ? lutl : nullptr, rho);
+        if (tid < TC && base + tid < n) {
+            ub_out[(size_t)g.z * n + base + tid] = sh.ub2[tid]; lb_out[(size_t)g.z * n + base + tid] = sh.lb2[tid];
+            ub_out[(size_t)g.w * n + base + tid] = sh.ub[tid];  lb_out[(size_t)g.w * n + base + tid] = sh.lb[tid];
+        }
+    } else {
+        sweep_tile<512, PPT, false, TC, true, false>(T, sh, px, py, pz, pw, prho, g.y >= 0, nullptr, row, rot, rho, T.code ? lutl : nullptr);
+        if (tid < TC && base + tid < n) { ub_out[(size_t)blockIdx.y * n + base + tid] = sh.ub[tid]; lb_out[(size_t)blockIdx.y * n + base + tid] = sh.lb[tid]; }
+    }
 }
 
 // lattice terms only, at n free translations (NLMAX per workgroup)
@@ -2066,11 +2118,12 @@ struct goicp_engine {
     HeapNode* d_heaps; int heap_cap; size_t heap_jobs; HeapNode* d_heap_big; int heap_big_cap;
     float* d_fpscratch; size_t fp_blocks;
     float* d_cubes; float* d_ub; float* d_lb; int cube_cap; int2* d_groups; std::vector<int2> groups_host;
+    int4* d_pairs; int4* d_groups4; int4 one_group; int npairs; int fuse;     // fused evaluation of (rot_level -1, rot_level >= 0) group pairs of one slot (k_eval_cubes_dual)
     float* d_dist; int* d_int; int* d_tie; float* d_lat; int lat_cap; int* d_cnt; float* d_fp;
     int block, ppt; size_t dyn_lds; size_t dyn_lds_bnb; int heap_lds_nodes; int rbuf_floats; int fp_lds;
     int resident_jobs;                       // search workgroups resident at once (CUs x occupancy of the chosen k_inner_bnb)
     int streamed; size_t stream_wgs, stream_rot_wgs;   // streaming path: scratch sized for this many resident workgroups (rows / rotated clouds)
-    int stagger;                             // phase stagger of the two workgroups of a CU (k_eval_cubes, just-in-time form): sleep repetitions, 0 = off
+    int eval_pad;                            // extra dynamic LDS bytes of the just-in-time sweep kernel (experiment knob GOICP_EVAL_PAD: 16384 leaves one workgroup per CU)
     int eval_nt;                             // cubes per workgroup tile of the just-in-time sweep kernel (experiment knob GOICP_EVAL_NT: 8, 4 or 2)
     int jit_bnb;                             // geometric searches of 1025..2048 points: k_inner_bnb<512, 4, false, false, true>
     // round-based search (k_fr_*): geometric searches of more than 1024 points
@@ -2082,6 +2135,7 @@ struct goicp_engine {
     unsigned max_pops;
     uint64_t n_cubes, n_lookups; double kernel_ms;
     std::string err, kernel_name;
+    std::vector<int4> pairs_host, groups4_host;
     unsigned long long code_escapes;          // cells of the coded grid that fall back to the float grid
 };
 
@@ -2285,7 +2339,7 @@ extern "C" int goicp_engine_create(const goicp_engine_desc* d, goicp_engine** ou
     h->d_heaps = nullptr; h->d_fpscratch = nullptr; h->heap_cap = 8192; h->heap_jobs = 0; h->fp_blocks = 0; h->d_heap_big = nullptr; h->heap_big_cap = 0;
     h->n_cubes = h->n_lookups = 0; h->kernel_ms = 0; h->max_pops = 200000000u;
     { const char* e = getenv("GOICP_EVAL_NT"); h->eval_nt = (e && (atoi(e) == 4 || atoi(e) == 2)) ? atoi(e) : 8; }
-    { const char* e = getenv("GOICP_STAGGER"); h->stagger = e ? atoi(e) : 5; }      // s_sleep(127) repetitions; 0 switches the stagger off
+    { const char* e = getenv("GOICP_EVAL_PAD"); h->eval_pad = e ? std::max(0, std::min(atoi(e), 60000)) : 0; }
     h->code_escapes = 0;
     h->fr_mode = 0; h->fr_st = nullptr; h->fr_heaps = nullptr; h->fr_exps = nullptr; h->fr_wl = nullptr; h->fr_cnt = nullptr; h->fr_parts = nullptr; h->fr_srot = nullptr; h->fr_results = nullptr;
     h->fr_jobs = 0; h->fr_cap_nodes = 0; h->fr_cap_exps = 0; h->fr_wl_cap = 0; h->fr_rounds = 0; h->fr_spec_cubes = 0;
@@ -2414,6 +2468,9 @@ extern "C" int goicp_engine_create(const goicp_engine_desc* d, goicp_engine** ou
     CR(dev_upload<goicp_bnb_job>(h, nullptr, h->job_cap, &h->d_jobs));
     CR(dev_upload<goicp_bnb_result>(h, nullptr, h->job_cap, &h->d_results));
     CR(dev_upload<int2>(h, nullptr, 4096, &h->d_groups));
+    CR(dev_upload<int4>(h, nullptr, 2048, &h->d_pairs)); h->npairs = 0;
+    CR(dev_upload<int4>(h, nullptr, 4096, &h->d_groups4));
+    { const char* e = getenv("GOICP_FUSE"); h->fuse = !(e && atoi(e) == 0); }      // A/B knob, read once per engine
     h->cube_cap = 1 << 16;
     CR(dev_upload<float>(h, nullptr, (size_t)4 * h->cube_cap, &h->d_cubes));
     CR(dev_upload<float>(h, nullptr, h->cube_cap, &h->d_ub));
@@ -2426,8 +2483,6 @@ extern "C" int goicp_engine_create(const goicp_engine_desc* d, goicp_engine** ou
     CR(dev_upload<int>(h, nullptr, h->lat_cap, &h->d_cnt));
     CR(dev_upload<float>(h, nullptr, h->lat_cap, &h->d_fp));
     { unsigned long long* p_t; CR(dev_upload<unsigned long long>(h, nullptr, 16, &p_t)); CRH(hipMemset(p_t, 0, 128)); T.dbg_times = p_t; }
-    T.cu_tickets = nullptr; T.stagger_sleeps = h->stagger;
-    if (h->stagger > 0) { unsigned* p_t; CR(dev_upload<unsigned>(h, nullptr, 8 * 256, &p_t)); T.cu_tickets = p_t; }
     pick_geometry(h);
     if (h->dyn_lds_bnb + sizeof(TileShm<1024>) + 64 > 160 * 1024) { h->err = "LDS budget exceeded"; CR(GOICP_ERR_ARG); }
     {
@@ -2563,8 +2618,24 @@ static int launch_eval(goicp_engine* h, int slot, int rot_level, const int2* gro
     // clouds of 1025..5120 points without penalty terms: 512 lanes x twice the points, the points fetched just in time instead of
     // held in registers -> 128 VGPRs, two workgroups per CU, one gathering while the other selects (3.89 -> 3.52 ms at C3)
     const bool jit = h->block == 1024 && h->ppt >= 2 && !h->T.exact && !h->T.use_compat && !h->T.use_fpfh && !(getenv("GOICP_JIT") && atoi(getenv("GOICP_JIT")) == 0);
-    if (jit && h->T.cu_tickets) HIPCHK(h, hipMemsetAsync(h->T.cu_tickets, 0, 8 * 256 * sizeof(unsigned), h->stream));
-#define CALLJ(P2) hipLaunchKernelGGL((k_eval_cubes<512, P2, TC, true>), dim3(tiles, ngroups), dim3(512), h->dyn_lds, h->stream, h->T, h->d_rot, slot, rot_level, groups_dev, (const float*)cubes_dev, n, (float*)ub_dev, (float*)lb_dev, h->d_fpscratch)
+#define CALLJ(P2) hipLaunchKernelGGL((k_eval_cubes<512, P2, TC, true>), dim3(tiles, ngroups), dim3(512), h->dyn_lds + (size_t)h->eval_pad, h->stream, h->T, h->d_rot, slot, rot_level, groups_dev, (const float*)cubes_dev, n, (float*)ub_dev, (float*)lb_dev, h->d_fpscratch)
+    if (jit && h->eval_nt == 8) {
+        // geometric just-in-time sweep: its own kernel; group pairs (no radius / radius, same slot) of a multi-group call fused when all pair up
+        const bool dual = groups_dev == h->d_groups && h->npairs > 0 && h->npairs * 2 == ngroups;
+        const int4* gtab = h->d_pairs;
+        if (!dual) {
+            // (single-group calls and unpaired tables: one int4 per group, staged here; the table of a repeated multi-group call is cached)
+            if (!groups_dev) { h->one_group = make_int4(slot, rot_level, 0, 0); HIPCHK(h, hipMemcpyAsync(h->d_pairs + 2047, &h->one_group, sizeof(int4), hipMemcpyHostToDevice, h->stream)); gtab = h->d_pairs + 2047; }
+            else gtab = h->d_groups4;
+        }
+#define CALLG(P2) do { if (dual) hipLaunchKernelGGL((k_eval_cubes_geo<P2, true>), dim3(tiles, h->npairs), dim3(512), 0, h->stream, h->T, h->d_rot, gtab, (const float*)cubes_dev, n, (float*)ub_dev, (float*)lb_dev); \
+                       else hipLaunchKernelGGL((k_eval_cubes_geo<P2, false>), dim3(tiles, ngroups), dim3(512), 0, h->stream, h->T, h->d_rot, gtab, (const float*)cubes_dev, n, (float*)ub_dev, (float*)lb_dev); } while (0)
+        if (h->ppt == 2) CALLG(4); else if (h->ppt == 4) CALLG(8); else CALLG(10);
+#undef CALLG
+        HIPCHK(h, hipGetLastError());
+        h->n_cubes += (uint64_t)n * ngroups; h->n_lookups += (uint64_t)n * ngroups * h->T.Nd;
+        return GOICP_OK;
+    }
 #define CALLJN(P2, NTT) hipLaunchKernelGGL((k_eval_cubes<512, P2, NTT, true>), dim3((n + NTT - 1) / NTT, ngroups), dim3(512), h->dyn_lds, h->stream, h->T, h->d_rot, slot, rot_level, groups_dev, (const float*)cubes_dev, n, (float*)ub_dev, (float*)lb_dev, h->d_fpscratch)
     if (jit && h->ppt == 2) CALLJ(4);
     else if (jit && h->ppt == 4) CALLJ(8);
@@ -2602,7 +2673,8 @@ extern "C" const char* goicp_engine_eval_kernel_name(goicp_engine* h) {
     char buf[96];
     const bool jit = h->block == 1024 && h->ppt >= 2 && !h->T.exact && !h->T.use_compat && !h->T.use_fpfh && !(getenv("GOICP_JIT") && atoi(getenv("GOICP_JIT")) == 0);
     if (h->streamed) snprintf(buf, sizeof buf, "k_eval_cubes_stream<%d>", h->T.Nd > 16384 ? 1024 : 512);
-    else if (jit) snprintf(buf, sizeof buf, "k_eval_cubes<512,%d,8,true>", 2 * h->ppt);
+    else if (jit && h->eval_nt == 8) snprintf(buf, sizeof buf, "k_eval_cubes_geo<%d,%s>", 2 * h->ppt, h->npairs > 0 ? "true" : "false");   // (true: the group table of the last multi-group call paired up)
+    else if (jit) snprintf(buf, sizeof buf, "k_eval_cubes<512,%d,%d,true>", 2 * h->ppt, h->eval_nt);
     else snprintf(buf, sizeof buf, "k_eval_cubes<%d,%d,8,false>", h->block, h->ppt);
     h->kernel_name = buf;
     return h->kernel_name.c_str();
@@ -2630,6 +2702,23 @@ extern "C" int goicp_engine_eval_cubes_multi_dev(goicp_engine* h, const int32_t*
         HIPCHK(h, hipStreamSynchronize(h->stream));
         h->groups_host = g;
         HIPCHK(h, hipMemcpyAsync(h->d_groups, h->groups_host.data(), (size_t)ngroups * sizeof(int2), hipMemcpyHostToDevice, h->stream));
+        h->groups4_host.resize((size_t)ngroups);
+        for (int k = 0; k < ngroups; k++) h->groups4_host[(size_t)k] = make_int4(g[k].x, g[k].y, k, k);
+        HIPCHK(h, hipMemcpyAsync(h->d_groups4, h->groups4_host.data(), (size_t)ngroups * sizeof(int4), hipMemcpyHostToDevice, h->stream));
+        // groups that share a slot, one without rotation uncertainty and one with: evaluated from one pass of gathers when ALL groups pair up
+        h->npairs = 0;
+        if (h->fuse && (ngroups & 1) == 0 && ngroups / 2 <= 2048) {
+            std::vector<int4> pairs; std::vector<char> used((size_t)ngroups, 0);
+            for (int a = 0; a < ngroups; a++) {
+                if (used[a] || g[a].y >= 0) continue;
+                for (int b = 0; b < ngroups; b++) if (!used[b] && b != a && g[b].x == g[a].x && g[b].y >= 0) { used[a] = used[b] = 1; pairs.push_back(make_int4(g[a].x, g[b].y, a, b)); break; }
+            }
+            if ((int)pairs.size() * 2 == ngroups) {
+                h->pairs_host = pairs;
+                HIPCHK(h, hipMemcpyAsync(h->d_pairs, h->pairs_host.data(), pairs.size() * sizeof(int4), hipMemcpyHostToDevice, h->stream));
+                h->npairs = (int)pairs.size();
+            }
+        }
     }
     return launch_eval(h, 0, -1, h->d_groups, ngroups, cubes_dev, n, ub_dev, lb_dev);
 }

@@ -401,6 +401,55 @@ def test_multi_group_launch_equals_single_launches():
     e.close()
 
 
+@pytest.mark.parametrize("n,trim", [(5000, 0.1), (3000, 0.0), (1500, 0.1)])
+def test_fused_group_pairs_equal_separate_launches(n, trim, monkeypatch):
+    """Clouds of 1025..5120 points, geometric error: a multi-group launch whose groups pair up (same rotation slot, one call without
+    rotation uncertainty and one with -- OuterBnB's ub / lb calls, jly_goicp.cpp:768,861) is evaluated from ONE pass of gathers
+    (k_eval_cubes_geo<.., true>); bounds must equal, bit for bit, the single-group launches and the unfused multi-group launch, and
+    the oracle within the large-cloud tolerance. Unpaired tables take the unfused kernel."""
+    import torch
+    S = 100
+    P = synth_pair(n, seed=20260401 + n)
+    v, _ = cfg_vector(distTransSize=S, trimFraction=trim, regularization=0.0, ponderation=0, MSEThresh=0.001)
+    o = oracle_for(P, v); o.initialize()
+    dist, near3, cc, _ = o.dt_dump()
+
+    def engine():
+        return goicp_amd.Engine(S=S, geom4=(o.geom[0], o.geom[2], o.geom[4], o.geom[6]), dist=dist, data_xyz=P["s"], weights=o.weights(),
+                                maxrotdis=o.maxrotdis(), model_xyz=P["t"], inlier_num=o.inlier_num(), do_trim=trim >= 0.001, norm=2, parity_mode=1)
+    rng = np.random.default_rng(n)
+    Rs = [o.axis_angle(rng.uniform(-2, 2, 3).astype(np.float32)) for _ in range(3)]
+    cubes = []
+    for L in (1, 2, 3, 4):
+        w = np.float32(1.0 / 2 ** L)
+        for a in rng.integers(0, 2 ** L, (10, 3)):
+            cubes.append([np.float32(-0.5) + a[0] * w, np.float32(-0.5) + a[1] * w, np.float32(-0.5) + a[2] * w, w])
+    cubes = np.array(cubes, np.float32); nc = len(cubes)
+    dc = torch.from_numpy(cubes).cuda()
+    outs = {}
+    for fuse in ("1", "0"):
+        monkeypatch.setenv("GOICP_FUSE", fuse)
+        e = engine()
+        for s_, R in enumerate(Rs):
+            e.set_rotation(s_, R)
+        assert e.eval_kernel_name().startswith("k_eval_cubes_geo")
+        for tag, slots, levels in (("paired", [0, 1, 0, 2, 1, 2], [-1, 4, 3, -1, -1, 0]), ("unpaired", [0, 1, 1], [-1, -1, 2])):
+            ub = torch.zeros((len(slots), nc), device="cuda"); lb = torch.zeros_like(ub)
+            e.eval_cubes_multi_dev(np.array(slots, np.int32), np.array(levels, np.int32), dc.data_ptr(), nc, ub.data_ptr(), lb.data_ptr())
+            e.synchronize()
+            outs[(fuse, tag)] = (ub.cpu().numpy(), lb.cpu().numpy())
+            if fuse == "1":
+                assert e.eval_kernel_name().endswith("true>" if tag == "paired" else "false>")
+                for g_, (sl, lv) in enumerate(zip(slots, levels)):
+                    u1, l1 = e.eval_cubes(sl, lv, cubes)
+                    assert np.array_equal(outs[(fuse, tag)][0][g_], u1) and np.array_equal(outs[(fuse, tag)][1][g_], l1)
+                    o.rotate(Rs[sl]); ou, ol = o.eval_cubes(lv, cubes)
+                    assert close(u1, ou, False, n) and close(l1, ol, False, n)
+        e.close()
+    for tag in ("paired", "unpaired"):
+        assert np.array_equal(outs[("1", tag)][0], outs[("0", tag)][0]) and np.array_equal(outs[("1", tag)][1], outs[("0", tag)][1])
+
+
 @pytest.mark.parametrize("n,S,trim", [(5000, 300, 0.1), (50000, 500, 0.0), (20000, 200, 0.1)])
 def test_full_size_properties(n, S, trim):
     """BASELINE config-3 shape (N=5000, 300^3 DT, trim 0.1), config-5 shape (N=50000, 500^3 DT, untrimmed; streamed

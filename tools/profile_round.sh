@@ -17,7 +17,7 @@ cd /tmp
 if [ "$SHAPE" = "c5" ]; then
   timeout -k 10 500 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- python3 $R/bench.py $ARGS --steps 5 --warmup 1 --no-cpu --no-register > $OUT/stats.log 2>&1
 else
-  timeout -k 10 500 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- python3 $R/bench.py --steps 20 --warmup 2 --no-cpu > $OUT/stats.log 2>&1
+  timeout -k 10 500 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- python3 $R/bench.py --steps 20 --warmup 2 --no-cpu --cavity-threads 1 --cavity-rows 64 --overlap-pairs 1 > $OUT/stats.log 2>&1     # (one host thread: rocprofv3 crashed in its launch interception with eight)
 fi
 timeout -k 10 400 rocprofv3 --kernel-trace --pmc FETCH_SIZE TCC_HIT_sum --output-format csv -d $OUT/pmc_a -- python3 $R/bench.py $ARGS --steps 2 --warmup 1 --no-cpu --no-register > $OUT/pmc_a.log 2>&1
 timeout -k 10 400 rocprofv3 --kernel-trace --pmc WRITE_SIZE TCC_MISS_sum TCP_TCC_READ_REQ_sum --output-format csv -d $OUT/pmc_b -- python3 $R/bench.py $ARGS --steps 2 --warmup 1 --no-cpu --no-register > $OUT/pmc_b.log 2>&1

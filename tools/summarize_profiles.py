@@ -28,6 +28,10 @@ for sub in ("pmc_a", "pmc_b", "pmc_c"):
                 for c, v in cs.items():
                     out["pmc"][k][c] = dict(n=len(v), avg=sum(v) / len(v))
 # HBM/fabric bytes per launch of the metric kernel, per the guide: FETCH_SIZE is in KB and counts 64-B requests
+out["hbm_bytes_per_launch_by_kernel"] = {}
+for k, cs in out["pmc"].items():
+    if "k_eval_cubes" in k and "FETCH_SIZE" in cs:
+        out["hbm_bytes_per_launch_by_kernel"][k.replace("void ", "").replace(", ", ",")] = (cs["FETCH_SIZE"]["avg"] + cs.get("WRITE_SIZE", {"avg": 0})["avg"]) * 1024.0
 for k, cs in out["pmc"].items():
     if "k_eval_cubes" in k and "FETCH_SIZE" in cs:
         fetch = cs["FETCH_SIZE"]["avg"] * 1024.0
@@ -37,8 +41,9 @@ for k, cs in out["pmc"].items():
         hit = cs.get("TCC_HIT_sum", {}).get("avg"); miss = cs.get("TCC_MISS_sum", {}).get("avg")
         if hit is not None and miss is not None and hit + miss > 0:
             out["l2_hit_rate"] = hit / (hit + miss)
-        out["fetch_note"] = ("FETCH_SIZE*1024 (+WRITE_SIZE*1024). The accesses are 4-byte gathers, i.e. 64-B requests, so the guide's x2 "
-                             "correction for wide 128-B streaming reads does not apply; the 108 MB grid is Infinity-Cache resident, so this is "
-                             "fabric-side traffic, an upper bound of HBM-device traffic.")
+        out["fetch_note"] = ("FETCH_SIZE*1024 + WRITE_SIZE*1024 per launch, from separate --pmc passes. The reads are 2- and 4-byte gathers, i.e. 64-B "
+                             "requests, so the guide's x2 correction for wide 128-B streaming reads does not apply. These are fabric-side bytes (L2 misses): "
+                             "a 300^3 grid (54 MB coded + 108 MB float) is Infinity-Cache resident, so they bound HBM-device traffic from above; "
+                             "a 500^3 grid (250 + 500 MB) is not.")
 json.dump(out, open(os.path.join(d, "%s_summary.json" % tag), "w"), indent=1)
 print(json.dumps(out)[:1500])
