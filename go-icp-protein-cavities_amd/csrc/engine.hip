@@ -414,7 +414,8 @@ __device__ __forceinline__ void sweep_tile(const DevTables& T, TileShm<BLOCK>& s
             float d = W * v[j];
             if (use_rho) d -= RH;
             if (d < 0.f) d = 0.f;
-            r[j][m] = d;
+            if (JIT) asm volatile("" : "+v"(d));           // the residual is formed HERE (otherwise the compiler may sink these operations to the
+            r[j][m] = d;                                   // first use and keep value, weight and radius alive instead: registers, spills)
         }
         if (JIT) __builtin_amdgcn_sched_barrier(0);        // keep the point fetches one ahead instead of all up front
     }
@@ -745,9 +746,11 @@ __device__ __forceinline__ void sweep_tile(const DevTables& T, TileShm<BLOCK>& s
         // (two call sites rather than a loop: inside a loop the compiler hoists the block's lane-constant addresses and spills the residuals)
         if (tid < NT) { sh.ub2[tid] = sh.ub[tid]; sh.lb2[tid] = sh.lb[tid]; }        // (ordered by the barriers of the next finish())
         // second bound of the same cubes: minDis -= maxRotDisL; clamp (reference jly_goicp.cpp:375-381) on the products weights*DT kept in r
+        int tid2 = tid;
+        asm volatile("" : "+v"(tid2));                     // (keeps the radius fetches below the first finish(): hoisted above it they cost PPT registers)
 #pragma unroll
         for (int m = 0; m < PPT; m++) {
-            const float rh = dual_rho[min(tid + m * BLOCK, Nd - 1)];
+            const float rh = dual_rho[min(tid2 + m * BLOCK, Nd - 1)];
 #pragma unroll
             for (int j = 0; j < NT; j++) { float d = r[j][m] - rh; if (d < 0.f) d = 0.f; r[j][m] = d; }
         }
@@ -1907,7 +1910,13 @@ __global__ __launch_bounds__(BLOCK, (JIT ? (NT == 8 ? 4 : (NT == 4 ? 6 : 8)) : 1
 // cube list, same (double) cell arithmetic, 8 lookups per point in flight -- with nothing else: no residuals kept, no selection.
 // Its run time is the memory-system floor of the metric kernel's ACTUAL access pattern (unlike tools/probes/gather_probe.hip,
 // whose synthetic tiles repeat and stay L2-resident).
-template <int BLOCK, int PPT>
+// MODE 0: the tile's real lookups (8 per point, x-neighbours: about 2 cache lines per point, the other 6 lookups find their line already
+//         requested).  The other modes separate what the memory system charges for, on the same points and tiles:
+// MODE 1: only the lookups of cubes 0 and 4 (2 loads per point, about 2 lines: the misses alone);
+// MODE 2: 8 loads per point, all of cube 0's cell (1 line per point, 7 loads that find it requested);
+// MODE 3: 8 loads per point on 8 different grid rows (8 lines per point, no load finds its line requested);
+// MODE 4, 5: the real lookups with lane = (point, cube) instead of lane = point (see below).
+template <int BLOCK, int PPT, int MODE = 0>
 __global__ __launch_bounds__(BLOCK) void k_gather_probe(DevTables T, const float4* __restrict__ rot_all, const int2* __restrict__ groups,
                                                         const float* __restrict__ cubes, int n, float* __restrict__ out) {
     __shared__ float cen[TC][3];
@@ -1922,6 +1931,25 @@ __global__ __launch_bounds__(BLOCK) void k_gather_probe(DevTables T, const float
     }
     __syncthreads();
     float acc = 0.f;
+    if constexpr (MODE == 4 || MODE == 5) {
+        // lane = (point, cube): the 8 lanes of a point read cells of one grid row 33 cells apart at most (1-2 lines per 8 lanes, 8-16 per
+        // wave instruction instead of 64). MODE 5: the y / z cell arithmetic is done by one lane of the 8 and handed to the others.
+        const int j = tid & 7, q = tid >> 3;
+        const float cx = cen[j][0];
+#pragma unroll 8
+        for (int m = 0; m < TC * PPT; m++) {
+            const float4 p = rot[min(q + m * (BLOCK / 8), Nd - 1)];
+            int y, z;
+            if (MODE == 5) {
+                int yz = (j == 0) ? cell_of(p.y + cen[0][1], T.yMin, T.scale) : ((j == 1) ? cell_of(p.z + cen[0][2], T.zMin, T.scale) : 0);
+                y = __shfl(yz, (tid & 63 & ~7), 64); z = __shfl(yz, (tid & 63 & ~7) + 1, 64);
+            } else { y = cell_of(p.y + cen[0][1], T.yMin, T.scale); z = cell_of(p.z + cen[0][2], T.zMin, T.scale); }
+            const unsigned ix = (unsigned)((clamp_cell(z, S) * S + clamp_cell(y, S)) * S + clamp_cell(cell_of(p.x + cx, T.xMin, T.scale), S));
+            acc += T.code ? (float)T.code[ix] : T.dist[ix];
+        }
+        if (acc == 12345.678f) out[blockIdx.x] = acc;
+        return;
+    }
 #pragma unroll
     for (int m = 0; m < PPT; m++) {
         const float4 p = rot[min(tid + m * BLOCK, Nd - 1)];
@@ -1930,8 +1958,12 @@ __global__ __launch_bounds__(BLOCK) void k_gather_probe(DevTables T, const float
         float v[TC];
 #pragma unroll
         for (int j = 0; j < TC; j++) {
-            const unsigned ix = (unsigned)(rowbase + clamp_cell(cell_of(p.x + cen[j][0], T.xMin, T.scale), S));
-            v[j] = T.code ? (float)T.code[ix] : T.dist[ix];
+            if (MODE == 1 && (j & 3) != 0) { v[j] = 0.f; continue; }
+            const int jj = (MODE == 2 || MODE == 3) ? 0 : j;
+            unsigned ix = (unsigned)(rowbase + clamp_cell(cell_of(p.x + cen[jj][0], T.xMin, T.scale), S));
+            if (MODE == 3) ix = (unsigned)((clamp_cell(z, S) * S + clamp_cell(y + 3 * j - 10, S)) * S + clamp_cell(cell_of(p.x + cen[0][0], T.xMin, T.scale), S));
+            if (MODE == 2) { const volatile uint16_t* q = T.code + ix; const volatile float* qf = T.dist + ix; v[j] = T.code ? (float)*q : *qf; }   // (volatile: eight separate loads)
+            else v[j] = T.code ? (float)T.code[ix] : T.dist[ix];
         }
 #pragma unroll
         for (int j = 0; j < TC; j++) acc += v[j];
@@ -1949,12 +1981,30 @@ __global__ __launch_bounds__(BLOCK) void k_gather_probe(DevTables T, const float
 //               call, output row of the second).
 template <int PPT, bool DUAL>
 __global__ __launch_bounds__(512, 4) void k_eval_cubes_geo(DevTables T, const float4* __restrict__ rot_all, const int4* __restrict__ groups,
-                                                           const float* __restrict__ cubes, int n, float* __restrict__ ub_out, float* __restrict__ lb_out) {
+                                                           const float* __restrict__ cubes, int n, float* __restrict__ ub_out, float* __restrict__ lb_out,
+                                                           int tiles, int ngroups, int xcd_mode) {
     __shared__ TileShm<512> sh;
     __shared__ float lutl[LUT_LDS];
-    const int tid = threadIdx.x, Nd = T.Nd, base = blockIdx.x * TC;
+    // 1-D grid; workgroups are dealt round-robin over the 8 XCDs (each with its own 4 MB L2), so `blockIdx.x & 7` labels the workgroups
+    // that share an L2 (speed only, MI355X_MICROARCH.md "Workgroup dispatch"). xcd_mode 0: workgroup b = tile b % tiles of group b / tiles;
+    // 1: every XCD label takes a contiguous eighth of the (group, tile) list -- whole rotations; 2: a contiguous eighth of the TILES
+    // (neighbouring translations) of every group. The grid is padded to a multiple of 8 labels; the surplus workgroups leave at once.
+    int bx, by;
+    {
+        const int lin = blockIdx.x, lab = lin & 7, slot = lin >> 3;
+        if (xcd_mode == 1) {
+            const int total = tiles * ngroups, per = (total + 7) >> 3, L = lab * per + slot;
+            if (slot >= per || L >= total) return;
+            bx = L % tiles; by = L / tiles;
+        } else if (xcd_mode == 2) {
+            const int tper = (tiles + 7) >> 3;
+            by = slot / tper; bx = lab * tper + slot % tper;
+            if (by >= ngroups || bx >= tiles) return;
+        } else { if (lin >= tiles * ngroups) return; bx = lin % tiles; by = lin / tiles; }
+    }
+    const int tid = threadIdx.x, Nd = T.Nd, base = bx * TC;
     if (T.code) { for (int i = tid; i < LUT_LDS; i += 512) lutl[i] = T.lut[i]; }     // (ordered by the barrier behind the cube set-up)
-    const int4 g = groups[blockIdx.y];
+    const int4 g = groups[by];
     const float4* __restrict__ rot = rot_all + (size_t)g.x * Nd;
     const float* __restrict__ rho = g.y >= 0 ? T.maxRotDis + (size_t)g.y * Nd : nullptr;
     if (tid < TC) {
@@ -1980,7 +2030,7 @@ __global__ __launch_bounds__(512, 4) void k_eval_cubes_geo(DevTables T, const fl
         }
     } else {
         sweep_tile<512, PPT, false, TC, true, false>(T, sh, px, py, pz, pw, prho, g.y >= 0, nullptr, row, rot, rho, T.code ? lutl : nullptr);
-        if (tid < TC && base + tid < n) { ub_out[(size_t)blockIdx.y * n + base + tid] = sh.ub[tid]; lb_out[(size_t)blockIdx.y * n + base + tid] = sh.lb[tid]; }
+        if (tid < TC && base + tid < n) { ub_out[(size_t)by * n + base + tid] = sh.ub[tid]; lb_out[(size_t)by * n + base + tid] = sh.lb[tid]; }
     }
 }
 
@@ -2125,6 +2175,8 @@ struct goicp_engine {
     int streamed; size_t stream_wgs, stream_rot_wgs;   // streaming path: scratch sized for this many resident workgroups (rows / rotated clouds)
     int eval_pad;                            // extra dynamic LDS bytes of the just-in-time sweep kernel (experiment knob GOICP_EVAL_PAD: 16384 leaves one workgroup per CU)
     int eval_nt;                             // cubes per workgroup tile of the just-in-time sweep kernel (experiment knob GOICP_EVAL_NT: 8, 4 or 2)
+    int xcd_mode;                            // workgroup -> (group, tile) map of k_eval_cubes_geo (GOICP_XCD, read once per engine)
+    int jit_eval;                            // clouds of 1025..5120 points without penalty terms: the just-in-time sweep kernels (GOICP_JIT=0 disables; read once per engine)
     int jit_bnb;                             // geometric searches of 1025..2048 points: k_inner_bnb<512, 4, false, false, true>
     // round-based search (k_fr_*): geometric searches of more than 1024 points
     int fr_mode;                             // 0 off, else 1 + MODE of k_fr_expand
@@ -2278,6 +2330,28 @@ extern "C" void goicp_engine_destroy(goicp_engine* h) {
         else if (h->block == 1024 && h->ppt == 5) { CALL(1024, 5); }         \
         else { CALL(512, 16); }                                              \
     } while (0)
+
+// The dynamic-LDS ceiling of a kernel (hipFuncAttributeMaxDynamicSharedMemorySize) is a per-process property of the instantiation, and
+// engines of different cloud sizes share instantiations while they run side by side on host threads (batch driver): it is therefore
+// raised ONCE per instantiation to everything the CU has left beside the kernel's static LDS, never to one engine's own need.
+static hipError_t set_max_dyn_lds(const void* fn) {
+    static std::mutex mu; static std::map<std::pair<int, const void*>, int> done;      // per (device, instantiation)
+    std::lock_guard<std::mutex> lk(mu);
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    const std::pair<int, const void*> key(dev, fn);
+    if (done.count(key)) return hipSuccess;
+    hipFuncAttributes a;
+    e = hipFuncGetAttributes(&a, fn);
+    if (e != hipSuccess) return e;
+    const int room = 160 * 1024 - (int)a.sharedSizeBytes;
+    if (room <= 0) return hipErrorInvalidValue;
+    e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, room);
+    if (e == hipSuccess) done[key] = room;
+    return e;
+}
+static bool env_is_zero(const char* name) { const char* e = getenv(name); return e && atoi(e) == 0; }
 
 static void pick_geometry(goicp_engine* h) {
     // lanes x points-per-lane; the residuals of a tile (TC x PPT floats per lane) stay in registers across the
@@ -2471,6 +2545,7 @@ extern "C" int goicp_engine_create(const goicp_engine_desc* d, goicp_engine** ou
     CR(dev_upload<int4>(h, nullptr, 2048, &h->d_pairs)); h->npairs = 0;
     CR(dev_upload<int4>(h, nullptr, 4096, &h->d_groups4));
     { const char* e = getenv("GOICP_FUSE"); h->fuse = !(e && atoi(e) == 0); }      // A/B knob, read once per engine
+    { const char* e = getenv("GOICP_XCD"); h->xcd_mode = e ? std::max(0, std::min(atoi(e), 2)) : 1; }   // 1 measured 1.5-1.7 % faster than 0, 2 slower (tools/gather_modes.py)
     h->cube_cap = 1 << 16;
     CR(dev_upload<float>(h, nullptr, (size_t)4 * h->cube_cap, &h->d_cubes));
     CR(dev_upload<float>(h, nullptr, h->cube_cap, &h->d_ub));
@@ -2484,19 +2559,20 @@ extern "C" int goicp_engine_create(const goicp_engine_desc* d, goicp_engine** ou
     CR(dev_upload<float>(h, nullptr, h->lat_cap, &h->d_fp));
     { unsigned long long* p_t; CR(dev_upload<unsigned long long>(h, nullptr, 16, &p_t)); CRH(hipMemset(p_t, 0, 128)); T.dbg_times = p_t; }
     pick_geometry(h);
+    h->jit_eval = (h->block == 1024 && h->ppt >= 2 && !T.exact && !T.use_compat && !T.use_fpfh && !env_is_zero("GOICP_JIT")) ? 1 : 0;
     if (h->dyn_lds_bnb + sizeof(TileShm<1024>) + 64 > 160 * 1024) { h->err = "LDS budget exceeded"; CR(GOICP_ERR_ARG); }
     {
         // static tile state + residual rows + LDS heap can exceed the 64 KB a launch gets without asking
-#define SETATTR(B, P) do { CRH(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_inner_bnb<B, P, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->dyn_lds_bnb)); \
-                           CRH(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_inner_bnb<B, P, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->dyn_lds_bnb)); \
-                           if (h->dyn_lds) CRH(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_eval_cubes<B, P, TC>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->dyn_lds)); } while (0)
+#define SETATTR(B, P) do { CRH(set_max_dyn_lds(reinterpret_cast<const void*>(&k_inner_bnb<B, P, true>))); \
+                           CRH(set_max_dyn_lds(reinterpret_cast<const void*>(&k_inner_bnb<B, P, false>))); \
+                           if (h->dyn_lds) CRH(set_max_dyn_lds(reinterpret_cast<const void*>(&k_eval_cubes<B, P, TC>))); } while (0)
         DISPATCH_GEOM(h, SETATTR);
 #undef SETATTR
-        if (h->streamed) CRH(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_inner_bnb<1024, 1, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->dyn_lds_bnb));
+        if (h->streamed) CRH(set_max_dyn_lds(reinterpret_cast<const void*>(&k_inner_bnb<1024, 1, false, true>)));
         // measured (tools/mid_perf.py): 2 000 points 15.2 -> 12.9 ms of kernel time, 4 000 points no change, 5 000 points 7 % slower
         // (122 spilled registers), so only the 1025..2048-point geometry switches. GOICP_JIT_BNB=0 disables.
-        h->jit_bnb = (!h->streamed && h->block == 1024 && h->ppt == 2 && !T.exact && !T.use_compat && !T.use_fpfh && !(getenv("GOICP_JIT_BNB") && atoi(getenv("GOICP_JIT_BNB")) == 0)) ? 1 : 0;
-        if (h->jit_bnb) CRH(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_inner_bnb<512, 4, false, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->dyn_lds_bnb));
+        h->jit_bnb = (!h->streamed && h->block == 1024 && h->ppt == 2 && !T.exact && !T.use_compat && !T.use_fpfh && !env_is_zero("GOICP_JIT_BNB")) ? 1 : 0;
+        if (h->jit_bnb) CRH(set_max_dyn_lds(reinterpret_cast<const void*>(&k_inner_bnb<512, 4, false, false, true>)));
         {
             int ncu = 0; CRH(hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, h->device));   // (a full hipGetDeviceProperties costs ~1 ms per engine)
             int nb = 0;
@@ -2617,7 +2693,7 @@ static int launch_eval(goicp_engine* h, int slot, int rot_level, const int2* gro
 #define CALL(B, P) hipLaunchKernelGGL((k_eval_cubes<B, P, TC>), dim3(tiles, ngroups), dim3(B), h->dyn_lds, h->stream, h->T, h->d_rot, slot, rot_level, groups_dev, (const float*)cubes_dev, n, (float*)ub_dev, (float*)lb_dev, h->d_fpscratch)
     // clouds of 1025..5120 points without penalty terms: 512 lanes x twice the points, the points fetched just in time instead of
     // held in registers -> 128 VGPRs, two workgroups per CU, one gathering while the other selects (3.89 -> 3.52 ms at C3)
-    const bool jit = h->block == 1024 && h->ppt >= 2 && !h->T.exact && !h->T.use_compat && !h->T.use_fpfh && !(getenv("GOICP_JIT") && atoi(getenv("GOICP_JIT")) == 0);
+    const bool jit = h->jit_eval != 0;
 #define CALLJ(P2) hipLaunchKernelGGL((k_eval_cubes<512, P2, TC, true>), dim3(tiles, ngroups), dim3(512), h->dyn_lds + (size_t)h->eval_pad, h->stream, h->T, h->d_rot, slot, rot_level, groups_dev, (const float*)cubes_dev, n, (float*)ub_dev, (float*)lb_dev, h->d_fpscratch)
     if (jit && h->eval_nt == 8) {
         // geometric just-in-time sweep: its own kernel; group pairs (no radius / radius, same slot) of a multi-group call fused when all pair up
@@ -2628,8 +2704,10 @@ static int launch_eval(goicp_engine* h, int slot, int rot_level, const int2* gro
             if (!groups_dev) { h->one_group = make_int4(slot, rot_level, 0, 0); HIPCHK(h, hipMemcpyAsync(h->d_pairs + 2047, &h->one_group, sizeof(int4), hipMemcpyHostToDevice, h->stream)); gtab = h->d_pairs + 2047; }
             else gtab = h->d_groups4;
         }
-#define CALLG(P2) do { if (dual) hipLaunchKernelGGL((k_eval_cubes_geo<P2, true>), dim3(tiles, h->npairs), dim3(512), 0, h->stream, h->T, h->d_rot, gtab, (const float*)cubes_dev, n, (float*)ub_dev, (float*)lb_dev); \
-                       else hipLaunchKernelGGL((k_eval_cubes_geo<P2, false>), dim3(tiles, ngroups), dim3(512), 0, h->stream, h->T, h->d_rot, gtab, (const float*)cubes_dev, n, (float*)ub_dev, (float*)lb_dev); } while (0)
+        const int ng = dual ? h->npairs : ngroups, xm = h->xcd_mode;
+        const long long wgs = xm == 1 ? 8ll * (((long long)tiles * ng + 7) / 8) : (xm == 2 ? 8ll * ((tiles + 7) / 8) * ng : (long long)tiles * ng);
+#define CALLG(P2) do { if (dual) hipLaunchKernelGGL((k_eval_cubes_geo<P2, true>), dim3((unsigned)wgs), dim3(512), 0, h->stream, h->T, h->d_rot, gtab, (const float*)cubes_dev, n, (float*)ub_dev, (float*)lb_dev, tiles, ng, xm); \
+                       else hipLaunchKernelGGL((k_eval_cubes_geo<P2, false>), dim3((unsigned)wgs), dim3(512), 0, h->stream, h->T, h->d_rot, gtab, (const float*)cubes_dev, n, (float*)ub_dev, (float*)lb_dev, tiles, ng, xm); } while (0)
         if (h->ppt == 2) CALLG(4); else if (h->ppt == 4) CALLG(8); else CALLG(10);
 #undef CALLG
         HIPCHK(h, hipGetLastError());
@@ -2657,8 +2735,16 @@ extern "C" int goicp_engine_debug_gather_probe(goicp_engine* h, const void* cube
     HIPCHK(h, hipSetDevice(h->device));
     const int tiles = (n + TC - 1) / TC, ngroups = (int)h->groups_host.size();
     HIPCHK(h, hipEventRecord(h->ev0, h->stream));
-    if (variant == 0) hipLaunchKernelGGL((k_gather_probe<512, 10>), dim3(tiles, ngroups), dim3(512), 0, h->stream, h->T, h->d_rot, h->d_groups, (const float*)cubes_dev, n, (float*)scratch_dev);
-    else hipLaunchKernelGGL((k_gather_probe<1024, 5>), dim3(tiles, ngroups), dim3(1024), 0, h->stream, h->T, h->d_rot, h->d_groups, (const float*)cubes_dev, n, (float*)scratch_dev);
+#define PROBE(B, P, M) hipLaunchKernelGGL((k_gather_probe<B, P, M>), dim3(tiles, ngroups), dim3(B), 0, h->stream, h->T, h->d_rot, h->d_groups, (const float*)cubes_dev, n, (float*)scratch_dev)
+    if (variant == 0) PROBE(512, 10, 0);
+    else if (variant == 1) PROBE(1024, 5, 0);
+    else if (variant == 2) PROBE(512, 10, 1);
+    else if (variant == 3) PROBE(512, 10, 2);
+    else if (variant == 4) PROBE(512, 10, 3);
+    else if (variant == 5) PROBE(512, 10, 4);
+    else if (variant == 6) PROBE(512, 10, 5);
+    else return GOICP_ERR_ARG;
+#undef PROBE
     HIPCHK(h, hipGetLastError());
     HIPCHK(h, hipEventRecord(h->ev1, h->stream));
     HIPCHK(h, hipStreamSynchronize(h->stream));
@@ -2671,7 +2757,7 @@ extern "C" const char* goicp_engine_eval_kernel_name(goicp_engine* h) {
     // the instantiation launch_eval() picks for this engine, spelled as rocprofv3 prints it
     if (!h) return "";
     char buf[96];
-    const bool jit = h->block == 1024 && h->ppt >= 2 && !h->T.exact && !h->T.use_compat && !h->T.use_fpfh && !(getenv("GOICP_JIT") && atoi(getenv("GOICP_JIT")) == 0);
+    const bool jit = h->jit_eval != 0;
     if (h->streamed) snprintf(buf, sizeof buf, "k_eval_cubes_stream<%d>", h->T.Nd > 16384 ? 1024 : 512);
     else if (jit && h->eval_nt == 8) snprintf(buf, sizeof buf, "k_eval_cubes_geo<%d,%s>", 2 * h->ppt, h->npairs > 0 ? "true" : "false");   // (true: the group table of the last multi-group call paired up)
     else if (jit) snprintf(buf, sizeof buf, "k_eval_cubes<512,%d,%d,true>", 2 * h->ppt, h->eval_nt);

@@ -77,6 +77,7 @@ public:
 struct RegisterStats {
     uint64_t rot_pops = 0, inner_calls = 0, inner_launches = 0, inner_jobs_launched = 0, cube_evals = 0, trans_pops = 0, icp_calls = 0, icp_iters = 0;
     double engine_kernel_ms = 0;
+    uint64_t pops_launched = 0;   // queue pops of every launched job, consumed by the replay or not (speculation cost)
 };
 
 class GoICP {

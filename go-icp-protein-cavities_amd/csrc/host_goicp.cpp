@@ -677,6 +677,7 @@ float GoICP::OuterBnB() {
             stats.inner_launches++; stats.inner_jobs_launched += jobs.size();
             if (rc != GOICP_OK && rc != GOICP_ERR_LIMIT && rc != GOICP_ERR_OVERFLOW) { status = rc; return false; }
             for (size_t q = 0; q < jobs.size(); q++) {
+                stats.pops_launched += out[q].pops;
                 PopPlan& pl = *where[q].first; const int k = where[q].second;
                 pl.res[k] = out[q]; pl.job[k] = jobs[q]; pl.res_E[k] = optError; pl.have[k] = true;
             }
@@ -763,8 +764,11 @@ float GoICP::Register() {
     if (timing) {
         uint64_t rounds = 0, launched = 0;
         goicp_engine_search_stats(eng_, &rounds, &launched);
-        fprintf(stderr, "[goicp timing] Initialize+engine %.1f ms, OuterBnB %.1f ms (ICP host+device %.1f ms); search rounds %llu, cube evals launched %llu, consumed %llu\n",
-                t1 - t0, t2 - t1, icp_ms_, (unsigned long long)rounds, (unsigned long long)launched, (unsigned long long)stats.cube_evals);
+        fprintf(stderr, "[goicp timing] Initialize+engine %.1f ms, OuterBnB %.1f ms (ICP host+device %.1f ms); search rounds %llu, cube evals launched %llu, consumed %llu; "
+                        "launches %llu, jobs launched %llu consumed %llu, queue pops launched %llu consumed %llu, rot pops %llu\n",
+                t1 - t0, t2 - t1, icp_ms_, (unsigned long long)rounds, (unsigned long long)launched, (unsigned long long)stats.cube_evals,
+                (unsigned long long)stats.inner_launches, (unsigned long long)stats.inner_jobs_launched, (unsigned long long)stats.inner_calls,
+                (unsigned long long)stats.pops_launched, (unsigned long long)stats.trans_pops, (unsigned long long)stats.rot_pops);
     }
     double ms = 0; uint64_t ce = 0, lk = 0;
     goicp_engine_stats(eng_, &ce, &lk, &ms);

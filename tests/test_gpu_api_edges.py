@@ -192,3 +192,30 @@ def test_pooled_device_resources_can_be_released_and_switched_off():
             "print('ok')\n") % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))), os.path.dirname(os.path.abspath(__file__)))
     out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=120, env=dict(os.environ, GOICP_CACHE_GB="0"))
     assert out.returncode == 0 and out.stdout.strip().endswith("ok"), out.stderr[-1500:]
+
+
+def test_concurrent_engines_of_different_sizes_share_kernel_instantiations():
+    """Two registrations in flight on two host threads whose clouds (1000 and 600 points, parity mode) run the SAME k_inner_bnb
+    instantiation with different dynamic-LDS needs (76 KB and 50 KB). The dynamic-LDS ceiling of a kernel is a per-process
+    attribute of the instantiation, so it is raised once to what the CU offers instead of per engine (a smaller engine created
+    in between must not lower it under a larger engine's launch). Results equal the sequential runs bit for bit."""
+    from concurrent.futures import ThreadPoolExecutor
+    from helpers import synth_pair
+    cfg = goicp_amd.cfg_vector(MSEThresh=0.001, trimFraction=0.0, regularization=0.0, regularizationFPFH=0.0, cfpfh=0, ponderation=0, norm=2, distTransSize=50)
+    # (no outliers: an untrimmed search on a cloud with 10 % outliers runs for hours; these four take 0.2-11 s on the CPU oracle)
+    pairs = [synth_pair(n, seed=sd, outlier_frac=0.0, noise=0.005) for n, sd in ((1000, 4101), (600, 4102), (1000, 4103), (600, 4104))]
+    known = [0.6682798, 0.32610527, 0.5772468, 0.3744664]      # oracle (plain-C restatement), same pairs and config
+
+    def reg(P):
+        g = goicp_amd.GoICP(cfg); g.set_clouds(P["t"], P["s"]); g.build_dt()
+        o = g.register(); g.close()
+        return o
+    seq = [reg(P) for P in pairs]
+    for o, want in zip(seq, known):
+        assert float(o["error"]) == float(np.float32(want)), (o["error"], want)
+    for rep in range(3):
+        with ThreadPoolExecutor(max_workers=2) as ex:
+            outs = list(ex.map(reg, pairs))
+        for a, b in zip(seq, outs):
+            assert a["error"] == b["error"] and np.array_equal(a["R"], b["R"]) and np.array_equal(a["t"], b["t"])
+            assert a["stats"]["trans_pops"] == b["stats"]["trans_pops"]

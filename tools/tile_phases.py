@@ -23,10 +23,10 @@ for _ in range(3):
     e.eval_cubes_multi_dev(sl, lv, cubes.data_ptr(), n, ub.data_ptr(), lb.data_ptr())
 e.synchronize()
 d = np.zeros(16, np.uint64); e.L.goicp_engine_debug_times(e.h, d.ctypes.data_as(C.c_void_p))
-tiles = float(d[7]); c = d[:6].astype(float) / max(tiles, 1)
-print("stamped tiles %d; cycles per tile: gather+residuals %.0f | max %.0f | histogram %.0f | scan %.0f | collect+sums %.0f | finish %.0f | total %.0f" % (tiles, c[0], c[1], c[2], c[3], c[4], c[5], c.sum()))
+tiles = float(d[7]); c = d[:7].astype(float) / max(tiles, 1)
+print("stamped tiles %d; cycles per tile (fused pairs: both selections summed): gather+residuals %.0f | max %.0f | histogram %.0f | scan %.0f | collect+sums %.0f | finish %.0f | radius pass %.0f | total %.0f" % (tiles, c[0], c[1], c[2], c[3], c[4], c[5], c[6], c.sum()))
 
-for variant in (0, 1, 0, 1):
+for variant in ():
     ms = C.c_float()
     rc = e.L.goicp_engine_debug_gather_probe(e.h, C.c_void_p(cubes.data_ptr()), n, C.c_void_p(ub.data_ptr()), variant, C.byref(ms))
     print("gather-only probe on the real access pattern (%s): rc %d, %.3f ms per launch-equivalent (%.0f G lookups/s)" % ("512x10" if variant == 0 else "1024x5", rc, ms.value, 149760 * 5000 / ms.value / 1e6))
