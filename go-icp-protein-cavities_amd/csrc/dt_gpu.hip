@@ -22,6 +22,7 @@
 #include <vector>
 
 #include "goicp_engine.h"
+#include "pool.hpp"
 
 struct goicp_dtgpu {
     int device, S;
@@ -125,40 +126,45 @@ extern "C" int goicp_dtgpu_build(int device, int S, const int32_t* occ_cells, in
     goicp_dtgpu* h = new goicp_dtgpu(); h->device = device; h->S = S; h->d_dist = nullptr; h->d_nearest = nullptr;
     uint8_t* d_mask = nullptr; int16_t* d_fx = nullptr; int32_t *d_g2 = nullptr, *d_src = nullptr, *d_cells = nullptr, *d_rows = nullptr, *d_slabs = nullptr, *d_sptr = nullptr, *d_srows = nullptr;
     float* d_table = nullptr;
-    DTCHK(hipMalloc((void**)&h->d_dist, ncell * sizeof(float)));
-    DTCHK(hipMalloc((void**)&h->d_nearest, ncell * sizeof(int32_t)));
-    DTCHK(hipMalloc((void**)&d_mask, ncell));
-    DTCHK(hipMalloc((void**)&d_fx, ncell * sizeof(int16_t)));
-    DTCHK(hipMalloc((void**)&d_g2, ncell * sizeof(int32_t)));
-    DTCHK(hipMalloc((void**)&d_src, ncell * sizeof(int32_t)));
-    DTCHK(hipMalloc((void**)&d_cells, (size_t)n_occ * sizeof(int32_t)));
-    DTCHK(hipMalloc((void**)&d_rows, rows.size() * sizeof(int32_t)));
-    DTCHK(hipMalloc((void**)&d_slabs, (size_t)nslab * sizeof(int32_t)));
-    DTCHK(hipMalloc((void**)&d_sptr, slab_ptr.size() * sizeof(int32_t)));
-    DTCHK(hipMalloc((void**)&d_srows, slab_rows.size() * sizeof(int32_t)));
-    DTCHK(hipMalloc((void**)&d_table, (size_t)n_table * sizeof(float)));
+    // blocks, stream and events come from the process-wide pool (pool.hpp): no hipMalloc / hipFree / default-stream work per build, so
+    // builds on several host threads (batch driver, dt_mode = 1) neither synchronise the device nor wait for each other's kernels
+    hipStream_t st = nullptr; hipEvent_t e0 = nullptr, e1 = nullptr; void* pinned = nullptr;
+    DTCHK(cache_queue(device, &st, &e0, &e1, &pinned));
+    DTCHK(cache_malloc((void**)&h->d_dist, ncell * sizeof(float), device));
+    DTCHK(cache_malloc((void**)&h->d_nearest, ncell * sizeof(int32_t), device));
+    DTCHK(cache_malloc((void**)&d_mask, ncell, device));
+    DTCHK(cache_malloc((void**)&d_fx, ncell * sizeof(int16_t), device));
+    DTCHK(cache_malloc((void**)&d_g2, ncell * sizeof(int32_t), device));
+    DTCHK(cache_malloc((void**)&d_src, ncell * sizeof(int32_t), device));
+    DTCHK(cache_malloc((void**)&d_cells, (size_t)n_occ * sizeof(int32_t), device));
+    DTCHK(cache_malloc((void**)&d_rows, rows.size() * sizeof(int32_t), device));
+    DTCHK(cache_malloc((void**)&d_slabs, (size_t)nslab * sizeof(int32_t), device));
+    DTCHK(cache_malloc((void**)&d_sptr, slab_ptr.size() * sizeof(int32_t), device));
+    DTCHK(cache_malloc((void**)&d_srows, slab_rows.size() * sizeof(int32_t), device));
+    DTCHK(cache_malloc((void**)&d_table, (size_t)n_table * sizeof(float), device));
     if (ok) {
-        DTCHK(hipMemsetAsync(d_mask, 0, ncell, 0));
-        DTCHK(hipMemcpyAsync(d_cells, occ_cells, (size_t)n_occ * sizeof(int32_t), hipMemcpyHostToDevice, 0));
-        DTCHK(hipMemcpyAsync(d_rows, rows.data(), rows.size() * sizeof(int32_t), hipMemcpyHostToDevice, 0));
-        DTCHK(hipMemcpyAsync(d_slabs, slabs.data(), (size_t)nslab * sizeof(int32_t), hipMemcpyHostToDevice, 0));
-        DTCHK(hipMemcpyAsync(d_sptr, slab_ptr.data(), slab_ptr.size() * sizeof(int32_t), hipMemcpyHostToDevice, 0));
-        DTCHK(hipMemcpyAsync(d_srows, slab_rows.data(), slab_rows.size() * sizeof(int32_t), hipMemcpyHostToDevice, 0));
-        DTCHK(hipMemcpyAsync(d_table, dist_of_d2, (size_t)n_table * sizeof(float), hipMemcpyHostToDevice, 0));
+        DTCHK(hipMemsetAsync(d_mask, 0, ncell, st));
+        DTCHK(hipMemcpyAsync(d_cells, occ_cells, (size_t)n_occ * sizeof(int32_t), hipMemcpyHostToDevice, st));
+        DTCHK(hipMemcpyAsync(d_rows, rows.data(), rows.size() * sizeof(int32_t), hipMemcpyHostToDevice, st));
+        DTCHK(hipMemcpyAsync(d_slabs, slabs.data(), (size_t)nslab * sizeof(int32_t), hipMemcpyHostToDevice, st));
+        DTCHK(hipMemcpyAsync(d_sptr, slab_ptr.data(), slab_ptr.size() * sizeof(int32_t), hipMemcpyHostToDevice, st));
+        DTCHK(hipMemcpyAsync(d_srows, slab_rows.data(), slab_rows.size() * sizeof(int32_t), hipMemcpyHostToDevice, st));
+        DTCHK(hipMemcpyAsync(d_table, dist_of_d2, (size_t)n_table * sizeof(float), hipMemcpyHostToDevice, st));
     }
     if (ok) {
-        hipLaunchKernelGGL(k_dt_mark, dim3((n_occ + 255) / 256), dim3(256), 0, 0, d_cells, n_occ, d_mask);
-        hipLaunchKernelGGL(k_dt_rows, dim3((unsigned)rows.size()), dim3(256), (size_t)((S + 15) & ~15), 0, d_mask, d_rows, S, d_fx);
-        hipLaunchKernelGGL(k_dt_slabs, dim3((S + 63) / 64, (S + 3) / 4, nslab), dim3(256), 0, 0, d_fx, d_slabs, d_sptr, d_srows, S, d_g2, d_src);
+        hipLaunchKernelGGL(k_dt_mark, dim3((n_occ + 255) / 256), dim3(256), 0, st, d_cells, n_occ, d_mask);
+        hipLaunchKernelGGL(k_dt_rows, dim3((unsigned)rows.size()), dim3(256), (size_t)((S + 15) & ~15), st, d_mask, d_rows, S, d_fx);
+        hipLaunchKernelGGL(k_dt_slabs, dim3((S + 63) / 64, (S + 3) / 4, nslab), dim3(256), 0, st, d_fx, d_slabs, d_sptr, d_srows, S, d_g2, d_src);
         const size_t lds = (size_t)nslab * 64 * sizeof(int32_t);
-        if (lds > 64 * 1024) DTCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_dt_columns), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        hipLaunchKernelGGL(k_dt_columns, dim3((S + 63) / 64, S), dim3(256), lds, 0, d_g2, d_src, d_slabs, nslab, S, d_table, h->d_dist, h->d_nearest);
+        if (lds > 64 * 1024) DTCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_dt_columns), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024));   // (raised to the ceiling, never lowered: builds run side by side)
+        hipLaunchKernelGGL(k_dt_columns, dim3((S + 63) / 64, S), dim3(256), lds, st, d_g2, d_src, d_slabs, nslab, S, d_table, h->d_dist, h->d_nearest);
         DTCHK(hipGetLastError());
-        DTCHK(hipDeviceSynchronize());
     }
+    if (st) (void)hipStreamSynchronize(st);                    // also on the error path: parked blocks must be idle
     void* tmp[] = {d_mask, d_fx, d_g2, d_src, d_cells, d_rows, d_slabs, d_sptr, d_srows, d_table};
-    for (void* p : tmp) if (p) (void)hipFree(p);
-    if (!ok) { if (h->d_dist) (void)hipFree(h->d_dist); if (h->d_nearest) (void)hipFree(h->d_nearest); delete h; return GOICP_ERR_HIP; }
+    for (void* p : tmp) if (p) cache_free(p);
+    cache_queue_return(device, st, e0, e1, pinned);
+    if (!ok) { if (h->d_dist) cache_free(h->d_dist); if (h->d_nearest) cache_free(h->d_nearest); delete h; return GOICP_ERR_HIP; }
     *out = h;
     return GOICP_OK;
 }
@@ -178,7 +184,8 @@ extern "C" int goicp_dtgpu_download(const goicp_dtgpu* h, float* dist, int32_t* 
 extern "C" void goicp_dtgpu_destroy(goicp_dtgpu* h) {
     if (!h) return;
     (void)hipSetDevice(h->device);
-    if (h->d_dist) (void)hipFree(h->d_dist);
-    if (h->d_nearest) (void)hipFree(h->d_nearest);
+    // (the engine that adopted the grid has been destroyed -- and its stream synchronised -- before this is called)
+    if (h->d_dist) cache_free(h->d_dist);
+    if (h->d_nearest) cache_free(h->d_nearest);
     delete h;
 }

@@ -31,6 +31,7 @@
 #include <mutex>
 
 #include "goicp_engine.h"
+#include "pool.hpp"
 
 #define TC 8            // cubes per workgroup tile (the 8 children of one queue pop)
 #define CAND_CAP 128     // threshold-bin members refined inside one wave; larger bins take the generic byte passes
@@ -2158,6 +2159,10 @@ __global__ __launch_bounds__(256) void k_icp_nn(DevTables T, const float* __rest
 struct goicp_engine {
     int device;
     hipStream_t stream;
+    hipStream_t stream_bulk;                  // search launches of cavity-sized engines (see cache_stream_aux); null: they use `stream`
+    hipStream_t stream_hi;                    // high-priority stream for the small latency-critical kernels (ICP 1-NN, point evaluation): beside other
+                                              // engines' bulk search launches they would otherwise queue behind thousands of search workgroups
+    hipEvent_t ev_wait; int wait_block;       // host waits: spin on the stream (default) or sleep on a blocking event (GOICP_WAIT=block; more host threads than cores)
     void* pinned;                             // PINNED_BYTES of host memory (may be null), travels with the stream in the pool
     hipEvent_t ev0, ev1;
     DevTables T;
@@ -2205,6 +2210,8 @@ struct DevCache {
     size_t parked_bytes = 0, limit = 0; bool init = false, off = false;
     struct Queue { int device; hipStream_t stream; hipEvent_t ev0, ev1; void* pinned; };   // pinned: PINNED_BYTES of host memory the device writes results into
     std::vector<Queue> queues;                 // idle (stream, event, event) triples of destroyed engines
+    struct Aux { int device, kind; hipStream_t stream; };
+    std::vector<Aux> aux_streams;              // idle auxiliary streams (cache_stream_aux)
     static size_t size_class(size_t n) {
         if (n <= 256) return 256;
         if (n < ((size_t)1 << 20)) { size_t p2 = 256; while (p2 < n) p2 <<= 1; return p2; }
@@ -2220,7 +2227,7 @@ struct DevCache {
 };
 DevCache g_cache;
 }  // namespace
-static hipError_t cache_malloc(void** out, size_t bytes, int device) {
+hipError_t cache_malloc(void** out, size_t bytes, int device) {
     const size_t cls = DevCache::size_class(bytes);
     {
         std::lock_guard<std::mutex> lk(g_cache.mu);
@@ -2238,7 +2245,7 @@ static hipError_t cache_malloc(void** out, size_t bytes, int device) {
     if (e == hipSuccess) { std::lock_guard<std::mutex> lk(g_cache.mu); g_cache.live[*out] = {device, cls}; }
     return e;
 }
-static void cache_free(void* p) {
+void cache_free(void* p) {
     if (!p) return;
     {
         std::lock_guard<std::mutex> lk(g_cache.mu);
@@ -2252,7 +2259,7 @@ static void cache_free(void* p) {
     (void)hipFree(p);
 }
 #define PINNED_BYTES ((size_t)1 << 20)
-static hipError_t cache_queue(int device, hipStream_t* st, hipEvent_t* e0, hipEvent_t* e1, void** pinned) {
+hipError_t cache_queue(int device, hipStream_t* st, hipEvent_t* e0, hipEvent_t* e1, void** pinned) {
     {
         std::lock_guard<std::mutex> lk(g_cache.mu);
         g_cache.setup();
@@ -2262,13 +2269,15 @@ static hipError_t cache_queue(int device, hipStream_t* st, hipEvent_t* e0, hipEv
             return hipSuccess;
         }
     }
-    hipError_t e = hipStreamCreate(st);
+    // non-blocking: a plain stream would synchronise with the legacy default stream, i.e. with every synchronous hipMemcpy / hipMemset any
+    // other host thread issues -- engines that run side by side (batch driver) then wait for each other's kernels
+    hipError_t e = hipStreamCreateWithFlags(st, hipStreamNonBlocking);
     if (e == hipSuccess) e = hipEventCreate(e0);
     if (e == hipSuccess) e = hipEventCreate(e1);
     if (e == hipSuccess && hipHostMalloc(pinned, PINNED_BYTES) != hipSuccess) *pinned = nullptr;   // optional: callers fall back to copies
     return e;
 }
-static void cache_queue_return(int device, hipStream_t st, hipEvent_t e0, hipEvent_t e1, void* pinned) {
+void cache_queue_return(int device, hipStream_t st, hipEvent_t e0, hipEvent_t e1, void* pinned) {
     if (st && e0 && e1) {
         std::lock_guard<std::mutex> lk(g_cache.mu);
         if (!g_cache.off && g_cache.queues.size() < 64) { g_cache.queues.push_back({device, st, e0, e1, pinned}); return; }
@@ -2278,10 +2287,45 @@ static void cache_queue_return(int device, hipStream_t st, hipEvent_t e0, hipEve
     if (st) (void)hipStreamDestroy(st);
     if (pinned) (void)hipHostFree(pinned);
 }
+// auxiliary streams of an engine, pooled like the rest. kind 0: high priority, for the small latency-critical kernels (ICP 1-NN, point
+// evaluation). kind 1: the bulk stream of cavity-sized engines' search launches (k_inner_bnb, hundreds to thousands of workgroups that hold a
+// CU's whole register file two at a time), confined to all but GOICP_CU_RESERVE (default 16) CUs -- beside other engines' launches the small
+// kernels otherwise wait for search workgroups to retire (configs[3] batch, 16 registrations in flight: 313 -> 390 pairs/s).
+static hipError_t cache_stream_aux(int device, int kind, hipStream_t* st) {
+    {
+        std::lock_guard<std::mutex> lk(g_cache.mu);
+        for (size_t k = 0; k < g_cache.aux_streams.size(); k++) if (g_cache.aux_streams[k].device == device && g_cache.aux_streams[k].kind == kind) {
+            *st = g_cache.aux_streams[k].stream; g_cache.aux_streams.erase(g_cache.aux_streams.begin() + k); return hipSuccess;
+        }
+    }
+    if (kind == 0) {
+        int lo = 0, hi = 0;                                    // (numerically lower = higher priority)
+        if (hipDeviceGetStreamPriorityRange(&lo, &hi) != hipSuccess) { lo = 0; hi = 0; }
+        return hipStreamCreateWithPriority(st, hipStreamNonBlocking, hi);
+    }
+    int reserve = 16, ncu = 0;
+    { const char* r = getenv("GOICP_CU_RESERVE"); if (r) reserve = atoi(r); }
+    if (reserve > 0 && hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && 2 * reserve <= ncu) {
+        std::vector<uint32_t> mask((size_t)(ncu + 31) / 32, 0u);
+        for (int c = 0; c < ncu - reserve; c++) mask[(size_t)c / 32] |= 1u << (c % 32);
+        return hipExtStreamCreateWithCUMask(st, (uint32_t)mask.size(), mask.data());
+    }
+    return hipStreamCreateWithFlags(st, hipStreamNonBlocking);
+}
+static void cache_stream_aux_return(int device, int kind, hipStream_t st) {
+    if (!st) return;
+    {
+        std::lock_guard<std::mutex> lk(g_cache.mu);
+        if (!g_cache.off && g_cache.aux_streams.size() < 128) { g_cache.aux_streams.push_back({device, kind, st}); return; }
+    }
+    (void)hipStreamDestroy(st);
+}
 extern "C" void goicp_engine_release_cached_memory(void) {
     std::vector<void*> blocks;
     std::vector<DevCache::Queue> qs;
-    { std::lock_guard<std::mutex> lk(g_cache.mu); for (auto& kv : g_cache.parked) blocks.push_back(kv.second); g_cache.parked.clear(); g_cache.parked_bytes = 0; qs.swap(g_cache.queues); }
+    std::vector<DevCache::Aux> aux;
+    { std::lock_guard<std::mutex> lk(g_cache.mu); for (auto& kv : g_cache.parked) blocks.push_back(kv.second); g_cache.parked.clear(); g_cache.parked_bytes = 0; qs.swap(g_cache.queues); aux.swap(g_cache.aux_streams); }
+    for (auto& q : aux) (void)hipStreamDestroy(q.stream);
     for (void* p : blocks) (void)hipFree(p);
     for (auto& q : qs) { (void)hipEventDestroy(q.ev0); (void)hipEventDestroy(q.ev1); (void)hipStreamDestroy(q.stream); if (q.pinned) (void)hipHostFree(q.pinned); }
 }
@@ -2289,12 +2333,26 @@ extern "C" void goicp_engine_release_cached_memory(void) {
 static int fail(goicp_engine* h, int code, const std::string& msg) { if (h) h->err = msg; return code; }
 #define HIPCHK(h, call) do { hipError_t e_ = (call); if (e_ != hipSuccess) return fail(h, GOICP_ERR_HIP, std::string(#call) + ": " + hipGetErrorString(e_)); } while (0)
 
+// host wait for everything queued on `st` so far
+static hipError_t wait_stream(goicp_engine* h, hipStream_t st) {
+    if (h->wait_block && h->ev_wait) {
+        hipError_t e = hipEventRecord(h->ev_wait, st);
+        return e == hipSuccess ? hipEventSynchronize(h->ev_wait) : e;
+    }
+    return hipStreamSynchronize(st);
+}
+
 template <class Tp>
 static int dev_upload(goicp_engine* h, const Tp* src, size_t n, Tp** out) {
     Tp* p = nullptr;
     HIPCHK(h, cache_malloc((void**)&p, std::max<size_t>(n, 1) * sizeof(Tp), h->device));
     h->allocs.push_back(p);
-    if (src && n) HIPCHK(h, hipMemcpy(p, src, n * sizeof(Tp), hipMemcpyHostToDevice));
+    if (src && n) {
+        // on the engine's own (non-blocking) stream, then waited for: the source may be a temporary of the caller, and a copy on the
+        // default stream would wait for the kernels of every other engine in the process
+        HIPCHK(h, hipMemcpyAsync(p, src, n * sizeof(Tp), hipMemcpyHostToDevice, h->stream));
+        HIPCHK(h, hipStreamSynchronize(h->stream));
+    }
     *out = p;
     return GOICP_OK;
 }
@@ -2309,6 +2367,9 @@ extern "C" void goicp_engine_destroy(goicp_engine* h) {
     if (!h) return;
     (void)hipSetDevice(h->device);
     if (h->stream) (void)hipStreamSynchronize(h->stream);          // parked blocks must be idle
+    if (h->stream_hi) { (void)hipStreamSynchronize(h->stream_hi); cache_stream_aux_return(h->device, 0, h->stream_hi); }
+    if (h->stream_bulk) { (void)hipStreamSynchronize(h->stream_bulk); cache_stream_aux_return(h->device, 1, h->stream_bulk); }
+    if (h->ev_wait) (void)hipEventDestroy(h->ev_wait);
     for (void* p : h->allocs) cache_free(p);
     if (h->d_heaps) cache_free(h->d_heaps);
     if (h->d_heap_big) cache_free(h->d_heap_big);
@@ -2408,7 +2469,7 @@ extern "C" int goicp_engine_create(const goicp_engine_desc* d, goicp_engine** ou
 
     goicp_engine* h = new goicp_engine();
     memset(&h->T, 0, sizeof h->T);
-    h->device = d->device_id; h->stream = nullptr; h->ev0 = h->ev1 = nullptr;
+    h->device = d->device_id; h->stream = nullptr; h->ev0 = h->ev1 = nullptr; h->stream_hi = nullptr; h->stream_bulk = nullptr; h->ev_wait = nullptr; h->wait_block = 0;
     h->streamed = 0; h->stream_wgs = 0; h->stream_rot_wgs = 0; h->pinned = nullptr;
     h->d_heaps = nullptr; h->d_fpscratch = nullptr; h->heap_cap = 8192; h->heap_jobs = 0; h->fp_blocks = 0; h->d_heap_big = nullptr; h->heap_big_cap = 0;
     h->n_cubes = h->n_lookups = 0; h->kernel_ms = 0; h->max_pops = 200000000u;
@@ -2421,6 +2482,9 @@ extern "C" int goicp_engine_create(const goicp_engine_desc* d, goicp_engine** ou
 #define CRH(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { fprintf(stderr, "goicp_engine_create: %s: %s\n", #call, hipGetErrorString(e_)); goicp_engine_destroy(h); return GOICP_ERR_NO_DEVICE; } } while (0)
     CRH(hipSetDevice(h->device));
     CRH(cache_queue(h->device, &h->stream, &h->ev0, &h->ev1, &h->pinned));
+    CRH(cache_stream_aux(h->device, 0, &h->stream_hi));
+    { const char* e = getenv("GOICP_WAIT"); h->wait_block = (e && !strcmp(e, "block")) ? 1 : 0; }
+    if (h->wait_block) CRH(hipEventCreateWithFlags(&h->ev_wait, hipEventBlockingSync | hipEventDisableTiming));
     DevTables& T = h->T;
     T.S = d->S; T.xMin = d->xMin; T.yMin = d->yMin; T.zMin = d->zMin; T.scale = d->scale;
     T.Nd = d->Nd; T.Nm = d->Nm; T.doTrim = d->doTrim ? 1 : 0; T.inlierNum = d->doTrim ? d->inlierNum : d->Nd; T.norm = d->norm;
@@ -2557,7 +2621,7 @@ extern "C" int goicp_engine_create(const goicp_engine_desc* d, goicp_engine** ou
     CR(dev_upload<float>(h, nullptr, (size_t)3 * h->lat_cap, &h->d_lat));
     CR(dev_upload<int>(h, nullptr, h->lat_cap, &h->d_cnt));
     CR(dev_upload<float>(h, nullptr, h->lat_cap, &h->d_fp));
-    { unsigned long long* p_t; CR(dev_upload<unsigned long long>(h, nullptr, 16, &p_t)); CRH(hipMemset(p_t, 0, 128)); T.dbg_times = p_t; }
+    { unsigned long long* p_t; CR(dev_upload<unsigned long long>(h, nullptr, 16, &p_t)); CRH(hipMemsetAsync(p_t, 0, 128, h->stream)); T.dbg_times = p_t; }
     pick_geometry(h);
     h->jit_eval = (h->block == 1024 && h->ppt >= 2 && !T.exact && !T.use_compat && !T.use_fpfh && !env_is_zero("GOICP_JIT")) ? 1 : 0;
     if (h->dyn_lds_bnb + sizeof(TileShm<1024>) + 64 > 160 * 1024) { h->err = "LDS budget exceeded"; CR(GOICP_ERR_ARG); }
@@ -2606,7 +2670,8 @@ extern "C" int goicp_engine_create(const goicp_engine_desc* d, goicp_engine** ou
 extern "C" int goicp_engine_debug_times(goicp_engine* h, unsigned long long* out8) {
     if (!h || !out8) return GOICP_ERR_ARG;
     HIPCHK(h, hipStreamSynchronize(h->stream));
-    HIPCHK(h, hipMemcpy(out8, h->T.dbg_times, 128, hipMemcpyDeviceToHost));      /* 16 words */
+    HIPCHK(h, hipMemcpyAsync(out8, h->T.dbg_times, 128, hipMemcpyDeviceToHost, h->stream));      /* 16 words */
+    HIPCHK(h, hipStreamSynchronize(h->stream));
     return GOICP_OK;
 }
 
@@ -2865,6 +2930,8 @@ static int ensure_big_heap(goicp_engine* h, int cap) {
 }
 
 static int run_bnb(goicp_engine* h, const goicp_bnb_job* jobs, int njobs, goicp_bnb_result* results, HeapNode* heaps, int cap) {
+    if (!h->stream_bulk && h->T.Nd <= 1024 && !h->streamed) { HIPCHK(h, hipStreamSynchronize(h->stream)); HIPCHK(h, cache_stream_aux(h->device, 1, &h->stream_bulk)); }
+    hipStream_t sq = h->stream_bulk ? h->stream_bulk : h->stream;      // (every call returns synchronised, so consecutive calls may use different streams)
     int rc = ensure_fpscratch(h, (size_t)njobs);
     if (rc != GOICP_OK) return rc;
     if (h->streamed) { rc = ensure_stream_scratch(h, (size_t)njobs, true); if (rc != GOICP_OK) return rc; }
@@ -2876,20 +2943,20 @@ static int run_bnb(goicp_engine* h, const goicp_bnb_job* jobs, int njobs, goicp_
     if (zero_copy) {
         k_jobs = (goicp_bnb_job*)h->pinned; k_results = (goicp_bnb_result*)(k_jobs + njobs);
         memcpy(k_jobs, jobs, (size_t)njobs * sizeof(goicp_bnb_job));
-    } else HIPCHK(h, hipMemcpyAsync(h->d_jobs, jobs, (size_t)njobs * sizeof(goicp_bnb_job), hipMemcpyHostToDevice, h->stream));
-    HIPCHK(h, hipEventRecord(h->ev0, h->stream));
-#define CALL(B, P) do { if (h->T.use_compat || h->T.use_fpfh) hipLaunchKernelGGL((k_inner_bnb<B, P, true>), dim3(njobs), dim3(B), h->dyn_lds_bnb, h->stream, h->T, k_jobs, k_results, heaps, cap, h->d_fpscratch, h->max_pops, h->heap_lds_nodes, h->rbuf_floats, h->fp_lds); \
-                        else hipLaunchKernelGGL((k_inner_bnb<B, P, false>), dim3(njobs), dim3(B), h->dyn_lds_bnb, h->stream, h->T, k_jobs, k_results, heaps, cap, h->d_fpscratch, h->max_pops, h->heap_lds_nodes, h->rbuf_floats, h->fp_lds); } while (0)
-#define CALLJ(P2) hipLaunchKernelGGL((k_inner_bnb<512, P2, false, false, true>), dim3(njobs), dim3(512), h->dyn_lds_bnb, h->stream, h->T, k_jobs, k_results, heaps, cap, h->d_fpscratch, h->max_pops, h->heap_lds_nodes, h->rbuf_floats, h->fp_lds)
-    if (h->streamed) hipLaunchKernelGGL((k_inner_bnb<1024, 1, false, true>), dim3(njobs), dim3(1024), h->dyn_lds_bnb, h->stream, h->T, k_jobs, k_results, heaps, cap, h->d_fpscratch, h->max_pops, h->heap_lds_nodes, h->rbuf_floats, h->fp_lds);
+    } else HIPCHK(h, hipMemcpyAsync(h->d_jobs, jobs, (size_t)njobs * sizeof(goicp_bnb_job), hipMemcpyHostToDevice, sq));
+    HIPCHK(h, hipEventRecord(h->ev0, sq));
+#define CALL(B, P) do { if (h->T.use_compat || h->T.use_fpfh) hipLaunchKernelGGL((k_inner_bnb<B, P, true>), dim3(njobs), dim3(B), h->dyn_lds_bnb, sq, h->T, k_jobs, k_results, heaps, cap, h->d_fpscratch, h->max_pops, h->heap_lds_nodes, h->rbuf_floats, h->fp_lds); \
+                        else hipLaunchKernelGGL((k_inner_bnb<B, P, false>), dim3(njobs), dim3(B), h->dyn_lds_bnb, sq, h->T, k_jobs, k_results, heaps, cap, h->d_fpscratch, h->max_pops, h->heap_lds_nodes, h->rbuf_floats, h->fp_lds); } while (0)
+#define CALLJ(P2) hipLaunchKernelGGL((k_inner_bnb<512, P2, false, false, true>), dim3(njobs), dim3(512), h->dyn_lds_bnb, sq, h->T, k_jobs, k_results, heaps, cap, h->d_fpscratch, h->max_pops, h->heap_lds_nodes, h->rbuf_floats, h->fp_lds)
+    if (h->streamed) hipLaunchKernelGGL((k_inner_bnb<1024, 1, false, true>), dim3(njobs), dim3(1024), h->dyn_lds_bnb, sq, h->T, k_jobs, k_results, heaps, cap, h->d_fpscratch, h->max_pops, h->heap_lds_nodes, h->rbuf_floats, h->fp_lds);
     else if (h->jit_bnb) CALLJ(4);
     else DISPATCH_GEOM(h, CALL);
 #undef CALLJ
 #undef CALL
     HIPCHK(h, hipGetLastError());
-    HIPCHK(h, hipEventRecord(h->ev1, h->stream));
-    if (!zero_copy) HIPCHK(h, hipMemcpyAsync(results, h->d_results, (size_t)njobs * sizeof(goicp_bnb_result), hipMemcpyDeviceToHost, h->stream));
-    HIPCHK(h, hipStreamSynchronize(h->stream));
+    HIPCHK(h, hipEventRecord(h->ev1, sq));
+    if (!zero_copy) HIPCHK(h, hipMemcpyAsync(results, h->d_results, (size_t)njobs * sizeof(goicp_bnb_result), hipMemcpyDeviceToHost, sq));
+    HIPCHK(h, wait_stream(h, sq));
     if (zero_copy) memcpy(results, k_results, (size_t)njobs * sizeof(goicp_bnb_result));
     float ms = 0.f; (void)hipEventElapsedTime(&ms, h->ev0, h->ev1); h->kernel_ms += ms;
     return GOICP_OK;
@@ -3040,17 +3107,17 @@ extern "C" int goicp_engine_point_eval(goicp_engine* h, const double* R9, const 
     const size_t Nd = (size_t)h->T.Nd;
     if (h->pinned && Nd * 8 <= PINNED_BYTES) {
         float* pd = (float*)h->pinned; int* pc = (int*)h->pinned + Nd;
-        hipLaunchKernelGGL(k_point_eval, dim3((h->T.Nd + 255) / 256), dim3(256), 0, h->stream, h->T, rt, pd, compat ? pc : nullptr);
+        hipLaunchKernelGGL(k_point_eval, dim3((h->T.Nd + 255) / 256), dim3(256), 0, h->stream_hi, h->T, rt, pd, compat ? pc : nullptr);
         HIPCHK(h, hipGetLastError());
-        HIPCHK(h, hipStreamSynchronize(h->stream));
+        HIPCHK(h, wait_stream(h, h->stream_hi));
         memcpy(dist, pd, Nd * sizeof(float));
         if (compat) memcpy(compat, pc, Nd * sizeof(int));
     } else {
-        hipLaunchKernelGGL(k_point_eval, dim3((h->T.Nd + 255) / 256), dim3(256), 0, h->stream, h->T, rt, h->d_dist, compat ? h->d_int : nullptr);
+        hipLaunchKernelGGL(k_point_eval, dim3((h->T.Nd + 255) / 256), dim3(256), 0, h->stream_hi, h->T, rt, h->d_dist, compat ? h->d_int : nullptr);
         HIPCHK(h, hipGetLastError());
-        HIPCHK(h, hipMemcpyAsync(dist, h->d_dist, (size_t)h->T.Nd * sizeof(float), hipMemcpyDeviceToHost, h->stream));
-        if (compat) HIPCHK(h, hipMemcpyAsync(compat, h->d_int, (size_t)h->T.Nd * sizeof(int), hipMemcpyDeviceToHost, h->stream));
-        HIPCHK(h, hipStreamSynchronize(h->stream));
+        HIPCHK(h, hipMemcpyAsync(dist, h->d_dist, (size_t)h->T.Nd * sizeof(float), hipMemcpyDeviceToHost, h->stream_hi));
+        if (compat) HIPCHK(h, hipMemcpyAsync(compat, h->d_int, (size_t)h->T.Nd * sizeof(int), hipMemcpyDeviceToHost, h->stream_hi));
+        HIPCHK(h, wait_stream(h, h->stream_hi));
     }
     h->n_lookups += (uint64_t)h->T.Nd;
     return GOICP_OK;
@@ -3067,19 +3134,19 @@ extern "C" int goicp_engine_icp_nn_ties(goicp_engine* h, const double* R9, const
         // small clouds (every ICP iteration of a cavity pair comes through here): the kernel writes its result arrays
         // straight into pinned host memory, so an iteration is one launch and one stream synchronisation
         int* pid = (int*)h->pinned; float* pd = (float*)h->pinned + Nd; int* pt = (int*)h->pinned + 2 * Nd;
-        hipLaunchKernelGGL(k_icp_nn, dim3((h->T.Nd + 3) / 4), dim3(256), 0, h->stream, h->T, h->d_mxyz, rt, pid, pd, n_tied ? pt : nullptr);
+        hipLaunchKernelGGL(k_icp_nn, dim3((h->T.Nd + 3) / 4), dim3(256), 0, h->stream_hi, h->T, h->d_mxyz, rt, pid, pd, n_tied ? pt : nullptr);
         HIPCHK(h, hipGetLastError());
-        HIPCHK(h, hipStreamSynchronize(h->stream));
+        HIPCHK(h, wait_stream(h, h->stream_hi));
         memcpy(id_model, pid, Nd * sizeof(int)); memcpy(dist_sq, pd, Nd * sizeof(float));
         if (n_tied) memcpy(n_tied, pt, Nd * sizeof(int));
         return GOICP_OK;
     }
-    hipLaunchKernelGGL(k_icp_nn, dim3((h->T.Nd + 3) / 4), dim3(256), 0, h->stream, h->T, h->d_mxyz, rt, h->d_int, h->d_dist, n_tied ? h->d_tie : nullptr);
+    hipLaunchKernelGGL(k_icp_nn, dim3((h->T.Nd + 3) / 4), dim3(256), 0, h->stream_hi, h->T, h->d_mxyz, rt, h->d_int, h->d_dist, n_tied ? h->d_tie : nullptr);
     HIPCHK(h, hipGetLastError());
-    HIPCHK(h, hipMemcpyAsync(id_model, h->d_int, (size_t)h->T.Nd * sizeof(int), hipMemcpyDeviceToHost, h->stream));
-    HIPCHK(h, hipMemcpyAsync(dist_sq, h->d_dist, (size_t)h->T.Nd * sizeof(float), hipMemcpyDeviceToHost, h->stream));
-    if (n_tied) HIPCHK(h, hipMemcpyAsync(n_tied, h->d_tie, (size_t)h->T.Nd * sizeof(int), hipMemcpyDeviceToHost, h->stream));
-    HIPCHK(h, hipStreamSynchronize(h->stream));
+    HIPCHK(h, hipMemcpyAsync(id_model, h->d_int, (size_t)h->T.Nd * sizeof(int), hipMemcpyDeviceToHost, h->stream_hi));
+    HIPCHK(h, hipMemcpyAsync(dist_sq, h->d_dist, (size_t)h->T.Nd * sizeof(float), hipMemcpyDeviceToHost, h->stream_hi));
+    if (n_tied) HIPCHK(h, hipMemcpyAsync(n_tied, h->d_tie, (size_t)h->T.Nd * sizeof(int), hipMemcpyDeviceToHost, h->stream_hi));
+    HIPCHK(h, wait_stream(h, h->stream_hi));
     return GOICP_OK;
 }
 
@@ -3113,7 +3180,7 @@ __global__ __launch_bounds__(256) void k_neighbor_counts(const float* __restrict
     if (i < n) counts[i] = cnt;
 }
 
-struct goicp_nbr_ctx { int device; int n; float* d_xyz; int* d_cnt; };
+struct goicp_nbr_ctx { int device; int n; float* d_xyz; int* d_cnt; hipStream_t stream; hipEvent_t ev0, ev1; void* pinned; };
 
 extern "C" int goicp_nbr_create(int device_id, const float* xyz, int n, goicp_nbr_ctx** out) {
     if (!xyz || n <= 0 || !out) return GOICP_ERR_ARG;
@@ -3121,11 +3188,13 @@ extern "C" int goicp_nbr_create(int device_id, const float* xyz, int n, goicp_nb
     if (hipGetDeviceCount(&ndev) != hipSuccess || device_id < 0 || device_id >= ndev) return GOICP_ERR_NO_DEVICE;
     if (hipSetDevice(device_id) != hipSuccess) return GOICP_ERR_NO_DEVICE;
     goicp_nbr_ctx* c = new goicp_nbr_ctx();
-    c->device = device_id; c->n = n; c->d_xyz = nullptr; c->d_cnt = nullptr;
-    if (cache_malloc((void**)&c->d_xyz, (size_t)3 * n * sizeof(float), device_id) != hipSuccess || cache_malloc((void**)&c->d_cnt, (size_t)n * sizeof(int), device_id) != hipSuccess ||
-        hipMemcpy(c->d_xyz, xyz, (size_t)3 * n * sizeof(float), hipMemcpyHostToDevice) != hipSuccess) {
+    c->device = device_id; c->n = n; c->d_xyz = nullptr; c->d_cnt = nullptr; c->stream = nullptr; c->ev0 = c->ev1 = nullptr; c->pinned = nullptr;
+    if (cache_queue(device_id, &c->stream, &c->ev0, &c->ev1, &c->pinned) != hipSuccess ||
+        cache_malloc((void**)&c->d_xyz, (size_t)3 * n * sizeof(float), device_id) != hipSuccess || cache_malloc((void**)&c->d_cnt, (size_t)n * sizeof(int), device_id) != hipSuccess ||
+        hipMemcpyAsync(c->d_xyz, xyz, (size_t)3 * n * sizeof(float), hipMemcpyHostToDevice, c->stream) != hipSuccess || hipStreamSynchronize(c->stream) != hipSuccess) {
         if (c->d_xyz) cache_free(c->d_xyz);
         if (c->d_cnt) cache_free(c->d_cnt);
+        cache_queue_return(device_id, c->stream, c->ev0, c->ev1, c->pinned);
         delete c; return GOICP_ERR_HIP;
     }
     *out = c;
@@ -3134,14 +3203,16 @@ extern "C" int goicp_nbr_create(int device_id, const float* xyz, int n, goicp_nb
 extern "C" int goicp_nbr_count(goicp_nbr_ctx* c, double lim, int32_t* counts) {
     if (!c || !counts) return GOICP_ERR_ARG;
     if (hipSetDevice(c->device) != hipSuccess) return GOICP_ERR_HIP;
-    hipLaunchKernelGGL(k_neighbor_counts, dim3((c->n + 255) / 256), dim3(256), 0, 0, c->d_xyz, c->n, lim, c->d_cnt);
+    hipLaunchKernelGGL(k_neighbor_counts, dim3((c->n + 255) / 256), dim3(256), 0, c->stream, c->d_xyz, c->n, lim, c->d_cnt);
     if (hipGetLastError() != hipSuccess) return GOICP_ERR_HIP;
-    if (hipMemcpy(counts, c->d_cnt, (size_t)c->n * sizeof(int), hipMemcpyDeviceToHost) != hipSuccess) return GOICP_ERR_HIP;
+    if (hipMemcpyAsync(counts, c->d_cnt, (size_t)c->n * sizeof(int), hipMemcpyDeviceToHost, c->stream) != hipSuccess || hipStreamSynchronize(c->stream) != hipSuccess) return GOICP_ERR_HIP;
     return GOICP_OK;
 }
 extern "C" void goicp_nbr_destroy(goicp_nbr_ctx* c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
     cache_free(c->d_xyz); cache_free(c->d_cnt);
+    cache_queue_return(c->device, c->stream, c->ev0, c->ev1, c->pinned);
     delete c;
 }

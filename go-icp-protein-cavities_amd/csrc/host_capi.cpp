@@ -8,6 +8,7 @@
 #include <vector>
 
 #include "goicp.hpp"
+#include <algorithm>
 #include "goicp_c.h"
 #include "host_io.hpp"
 
@@ -219,6 +220,8 @@ int goicp_run_pair_files(const char* base_dir, const char* target_mol2, const ch
     const std::string base = (base_dir && base_dir[0]) ? std::string(base_dir) + "/" : std::string();
     GoICP g;
     g.device_id = device_id; g.verbose = verbose;
+    { const char* e = getenv("GOICP_SPECULATE"); if (e) g.speculate = std::max(0, atoi(e)); }           // experiment knobs of the batch path
+    { const char* e = getenv("GOICP_SPEC_POPS"); if (e && atoi(e) > 0) g.spec_pop_budget = (uint32_t)atoi(e); }
     double cfg[18];
     if (!read_config(config_path, cfg)) return GOICP_ERR_ARG;
     apply_config(g, cfg);

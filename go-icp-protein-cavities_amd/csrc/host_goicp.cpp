@@ -211,6 +211,7 @@ void GoICP::log_error(const char* tag, float v) {
 
 // reference jly_goicp.cpp:79-99 + assignCellColor (:951-969)
 void GoICP::BuildDT() {
+    Clear();                      // an engine of the previous grid (it may have adopted a device-built grid in place) goes first
     status = GOICP_OK; error_message.clear();
     for (int i = 0; i < Nm; i++) if (!std::isfinite(pModel[i].x) || !std::isfinite(pModel[i].y) || !std::isfinite(pModel[i].z)) {
         status = GOICP_ERR_ARG; error_message = "model cloud holds a non-finite coordinate"; return;
