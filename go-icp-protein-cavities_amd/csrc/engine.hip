@@ -32,6 +32,7 @@
 
 #include "goicp_engine.h"
 #include "pool.hpp"
+#include "kabsch.hpp"
 
 #define TC 8            // cubes per workgroup tile (the 8 children of one queue pop)
 #define CAND_CAP 128     // threshold-bin members refined inside one wave; larger bins take the generic byte passes
@@ -2154,6 +2155,149 @@ __global__ __launch_bounds__(256) void k_icp_nn(DevTables T, const float* __rest
 }
 
 // ---------------------------------------------------------------------------------------------
+// k_icp_loop: ICP3D<float>::Run (reference jly_icp3d.hpp:197-311) as ONE launch for cavity-sized, untrimmed clouds: the whole
+// iteration -- exhaustive 1-NN (the search of k_icp_nn), the running centroids (never reset, divided by n: the reference's quirks), the
+// error sum, the 3x3 covariance, Kabsch and the pose update -- repeats inside one workgroup until the reference's stop test fires. Every
+// sum whose order matters runs sequentially over the point index on its own lane (7 + 9 chains), so the poses and the error are the bits
+// the host loop (host_goicp.cpp: icp_run) produces. Why: an iteration used to be one launch + one synchronisation; beside other engines'
+// search launches (batch driver) that round trip took 180 us instead of 20 us and ICP was 60 % of a cavity registration.
+// An iteration that meets an exact distance tie between model points is NOT decided here (the reference's kd-tree order decides it,
+// host_kdorder.hpp): the kernel returns the state before that iteration with status 1 and the host loop carries on from it.
+// ---------------------------------------------------------------------------------------------
+struct IcpState { double R[9], t[3], mu_m[3], mu_d[3]; float err, err_new; int iters, status; };
+__global__ __launch_bounds__(1024) void k_icp_loop(DevTables T, const float* __restrict__ mxyz, IcpState st0, float err_diff, int max_iters,
+                                                    IcpState* __restrict__ st_out, int* __restrict__ ids_out, float* __restrict__ dsq_out) {
+    extern __shared__ float icp_lds[];
+    const int n = T.Nd, Nm = T.Nm, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, NWV = blockDim.x >> 6;
+    float* mx = icp_lds;                  // [3 Nm] model
+    float* pd = mx + 3 * Nm;              // [3 n]  R*d + t of the current pose (float expression of jly_icp3d.hpp:239-241)
+    float* pm = pd + 3 * n;               // [3 n]  matched model point
+    float* dsq = pm + 3 * n;              // [n]
+    int* ids = reinterpret_cast<int*>(dsq + n);
+    __shared__ double sR[9], st[3], smu_m[3], smu_d[3], sH[9];
+    __shared__ float serr, serr_new;
+    __shared__ int sties, sstop;
+    for (int k = tid; k < 3 * Nm; k += blockDim.x) mx[k] = mxyz[k];
+    if (tid == 0) {
+        for (int k = 0; k < 9; k++) sR[k] = st0.R[k];
+        for (int k = 0; k < 3; k++) { st[k] = st0.t[k]; smu_m[k] = st0.mu_m[k]; smu_d[k] = st0.mu_d[k]; }
+        serr = st0.err; serr_new = st0.err_new; sties = 0; sstop = 0;
+    }
+    __syncthreads();
+    int iters = st0.iters, status = 0;
+    for (;;) {
+        if (iters >= max_iters) { status = 2; break; }
+        iters++;
+        // ---- correspondences: one wave per query, lanes over the model points (same arithmetic and reduction as k_icp_nn)
+        const float r00 = (float)sR[0], r01 = (float)sR[1], r02 = (float)sR[2], r10 = (float)sR[3], r11 = (float)sR[4], r12 = (float)sR[5];
+        const float r20 = (float)sR[6], r21 = (float)sR[7], r22 = (float)sR[8], t0 = (float)st[0], t1 = (float)st[1], t2 = (float)st[2];
+        for (int i = wave; i < n; i += NWV) {
+            const float d0 = T.dxyz[3 * i], d1 = T.dxyz[3 * i + 1], d2 = T.dxyz[3 * i + 2];
+            const float q0 = r00 * d0 + r01 * d1 + r02 * d2 + t0;
+            const float q1 = r10 * d0 + r11 * d1 + r12 * d2 + t1;
+            const float q2 = r20 * d0 + r21 * d1 + r22 * d2 + t2;
+            float best = INFINITY; int bi = 0x7fffffff, cnt = 0;
+            for (int m = lane; m < Nm; m += 64) {
+                const float e0 = q0 - mx[3 * m], e1 = q1 - mx[3 * m + 1], e2 = q2 - mx[3 * m + 2];
+                const float d = e0 * e0 + e1 * e1 + e2 * e2;
+                if (d < best) { best = d; bi = m; cnt = 1; }
+                else if (d == best) cnt++;
+            }
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) {
+                const float ob = __shfl_down(best, off, 64); const int oi = __shfl_down(bi, off, 64); const int oc = __shfl_down(cnt, off, 64);
+                if (ob < best) { best = ob; bi = oi; cnt = oc; }
+                else if (ob == best) { cnt += oc; if (oi < bi) bi = oi; }
+            }
+            if (lane == 0) {
+                ids[i] = bi; dsq[i] = best;
+                pd[3 * i] = q0; pd[3 * i + 1] = q1; pd[3 * i + 2] = q2;
+                pm[3 * i] = mx[3 * bi]; pm[3 * i + 1] = mx[3 * bi + 1]; pm[3 * i + 2] = mx[3 * bi + 2];
+                if (cnt > 1) sties = 1;
+            }
+        }
+        __syncthreads();
+        if (sties) { status = 1; iters--; break; }            // this iteration belongs to the host (kd-tree order among tied model points)
+        // ---- the seven running sums, each sequential over the point index on a lane of its own (jly_icp3d.hpp:256-276)
+        if (tid < 6) {
+            const float* src = tid < 3 ? pm + tid : pd + (tid - 3);
+            double acc = tid < 3 ? smu_m[tid] : smu_d[tid - 3];
+            int i = 0;
+            for (; i + 8 <= n; i += 8) {
+                float v[8];
+#pragma unroll
+                for (int q = 0; q < 8; q++) v[q] = src[3 * (i + q)];
+#pragma unroll
+                for (int q = 0; q < 8; q++) acc += (double)v[q];
+            }
+            for (; i < n; i++) acc += (double)src[3 * i];
+            if (tid < 3) smu_m[tid] = acc; else smu_d[tid - 3] = acc;
+        } else if (tid == 6) {
+            float e = 0.f;
+            int i = 0;
+            for (; i + 8 <= n; i += 8) {
+                float v[8];
+#pragma unroll
+                for (int q = 0; q < 8; q++) v[q] = dsq[i + q];
+#pragma unroll
+                for (int q = 0; q < 8; q++) e = (float)((double)e + (double)v[q]);
+            }
+            for (; i < n; i++) e = (float)((double)e + (double)dsq[i]);
+            serr_new = e;
+        }
+        __syncthreads();
+        if (tid == 0) {
+            const float err = serr, err_new = serr_new;
+            if (err > 0 && err - err_new < err_diff * n) sstop = 1;            // jly_icp3d.hpp:272 (num = n: untrimmed)
+            else {
+                serr = err_new;
+                for (int k = 0; k < 3; k++) { smu_m[k] = smu_m[k] / (double)(float)n; smu_d[k] = smu_d[k] / (double)(float)n; }
+            }
+        }
+        __syncthreads();
+        if (sstop) { status = 0; break; }
+        // ---- covariance: nine sequential chains (jly_icp3d.hpp:281)
+        if (tid < 9) {
+            const int a = tid / 3, b = tid % 3;
+            const double ma = smu_d[a], mb = smu_m[b];
+            double acc = 0;
+            int i = 0;
+            for (; i + 8 <= n; i += 8) {
+                float va[8], vb[8];
+#pragma unroll
+                for (int q = 0; q < 8; q++) { va[q] = pd[3 * (i + q) + a]; vb[q] = pm[3 * (i + q) + b]; }
+#pragma unroll
+                for (int q = 0; q < 8; q++) acc += ((double)va[q] - ma) * ((double)vb[q] - mb);
+            }
+            for (; i < n; i++) acc += ((double)pd[3 * i + a] - ma) * ((double)pm[3 * i + b] - mb);
+            sH[tid] = acc;
+        }
+        __syncthreads();
+        if (tid == 0) {
+            double H[9], Rn[9], Rd[9], Rc[9], td[3], tc[3], t_[3], mum[3], mud[3];
+            for (int k = 0; k < 9; k++) { H[k] = sH[k]; Rd[k] = sR[k]; }
+            for (int k = 0; k < 3; k++) { td[k] = st[k]; mum[k] = smu_m[k]; mud[k] = smu_d[k]; }
+            goicp::kabsch_rotation(H, Rn);
+            for (int a = 0; a < 3; a++) { double s_ = 0; for (int k = 0; k < 3; k++) s_ += Rn[3 * a + k] * mud[k]; t_[a] = mum[a] - s_; }
+            goicp::mul3(Rn, Rd, Rc);
+            for (int a = 0; a < 3; a++) { double s_ = 0; for (int k = 0; k < 3; k++) s_ += Rn[3 * a + k] * td[k]; tc[a] = s_ + t_[a]; }
+            for (int k = 0; k < 9; k++) sR[k] = Rc[k];
+            for (int k = 0; k < 3; k++) st[k] = tc[k];
+        }
+        __syncthreads();
+    }
+    __syncthreads();
+    for (int i = tid; i < n; i += blockDim.x) { ids_out[i] = ids[i]; dsq_out[i] = dsq[i]; }
+    if (tid == 0) {
+        IcpState o;
+        for (int k = 0; k < 9; k++) o.R[k] = sR[k];
+        for (int k = 0; k < 3; k++) { o.t[k] = st[k]; o.mu_m[k] = smu_m[k]; o.mu_d[k] = smu_d[k]; }
+        o.err = serr; o.err_new = serr_new; o.iters = iters; o.status = status;
+        *st_out = o;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------------------------
 struct goicp_engine {
@@ -2480,6 +2624,15 @@ extern "C" int goicp_engine_create(const goicp_engine_desc* d, goicp_engine** ou
     h->fr_jobs = 0; h->fr_cap_nodes = 0; h->fr_cap_exps = 0; h->fr_wl_cap = 0; h->fr_rounds = 0; h->fr_spec_cubes = 0;
 #define CR(call) do { int rc_ = (call); if (rc_ != GOICP_OK) { std::string m = h->err; goicp_engine_destroy(h); fprintf(stderr, "goicp_engine_create: %s\n", m.c_str()); return rc_; } } while (0)
 #define CRH(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { fprintf(stderr, "goicp_engine_create: %s: %s\n", #call, hipGetErrorString(e_)); goicp_engine_destroy(h); return GOICP_ERR_NO_DEVICE; } } while (0)
+    {   // experiment knob: how this process's host threads wait for the device (spin is the runtime's default with idle cores)
+        static std::once_flag sched_once;
+        std::call_once(sched_once, [] {
+            const char* e = getenv("GOICP_SCHED");
+            if (e && !strcmp(e, "yield")) (void)hipSetDeviceFlags(hipDeviceScheduleYield);
+            else if (e && !strcmp(e, "block")) (void)hipSetDeviceFlags(hipDeviceScheduleBlockingSync);
+            (void)hipGetLastError();
+        });
+    }
     CRH(hipSetDevice(h->device));
     CRH(cache_queue(h->device, &h->stream, &h->ev0, &h->ev1, &h->pinned));
     CRH(cache_stream_aux(h->device, 0, &h->stream_hi));
@@ -3147,6 +3300,25 @@ extern "C" int goicp_engine_icp_nn_ties(goicp_engine* h, const double* R9, const
     HIPCHK(h, hipMemcpyAsync(dist_sq, h->d_dist, (size_t)h->T.Nd * sizeof(float), hipMemcpyDeviceToHost, h->stream_hi));
     if (n_tied) HIPCHK(h, hipMemcpyAsync(n_tied, h->d_tie, (size_t)h->T.Nd * sizeof(int), hipMemcpyDeviceToHost, h->stream_hi));
     HIPCHK(h, wait_stream(h, h->stream_hi));
+    return GOICP_OK;
+}
+
+static_assert(sizeof(IcpState) == sizeof(goicp_icp_state), "goicp_icp_state");
+extern "C" int goicp_engine_icp_loop(goicp_engine* h, goicp_icp_state* state, float err_diff, int max_iters, int32_t* id_model, float* dist_sq) {
+    if (!h || !state || !id_model || !dist_sq || max_iters < 0) return GOICP_ERR_ARG;
+    const size_t n = (size_t)h->T.Nd, nm = (size_t)h->T.Nm;
+    const size_t lds = (3 * nm + 8 * n) * sizeof(float);
+    // cavity class only: untrimmed, everything in one workgroup's LDS, results through the pinned buffer
+    if (h->T.doTrim || h->T.Nm <= 0 || n > 1024 || nm > 2048 || lds > 60 * 1024 || !h->pinned || sizeof(IcpState) + 8 * n + 64 > PINNED_BYTES) return GOICP_ERR_ARG;
+    HIPCHK(h, hipSetDevice(h->device));
+    IcpState st0; memcpy(&st0, state, sizeof st0);
+    IcpState* po = (IcpState*)h->pinned;
+    int* pid = (int*)((char*)h->pinned + ((sizeof(IcpState) + 63) & ~(size_t)63)); float* pdq = (float*)(pid + n);
+    hipLaunchKernelGGL(k_icp_loop, dim3(1), dim3(1024), lds, h->stream_hi, h->T, h->d_mxyz, st0, err_diff, max_iters, po, pid, pdq);
+    HIPCHK(h, hipGetLastError());
+    HIPCHK(h, wait_stream(h, h->stream_hi));
+    memcpy(state, po, sizeof st0);
+    memcpy(id_model, pid, n * sizeof(int)); memcpy(dist_sq, pdq, n * sizeof(float));
     return GOICP_OK;
 }
 

@@ -120,6 +120,7 @@ public:
     int parity_mode = 1;          // see goicp_engine_desc::parity_mode
     int dt_mode = 0;              // 0: DT3D::Build restated on the host (bit-identical to the reference grid); 1: exact Euclidean transform built on the device (opt-in, see csrc/dt_gpu.hip)
     int speculate = 128;           // 0: one InnerBnB per launch; 1: the <=16 calls of a rotation pop per launch; M>1: also those of the next M-1 queue nodes
+    bool device_icp = true;       // untrimmed cavity-sized clouds: ICP3D::Run as one launch (goicp_engine_icp_loop); false: one launch per iteration
     uint32_t spec_pop_budget = 20000;   // queue-pop budget of a speculative job (re-run unbounded if it turns out to be needed)
     int verbose = 0;              // echo the reference's "Error*: ..." progress lines to stdout
     int status = GOICP_OK;        // last engine status
@@ -163,7 +164,6 @@ private:
 // jly_sorting.hpp:229-313 restated (the permutation fixes the float summation order of trimmed sums)
 void intro_select(float* data, size_t st, size_t en, size_t k);
 // V*diag(1,1,det)*U^T of the cross-covariance H = U W V^T (jly_icp3d.hpp:283-303)
-void kabsch_rotation(const double H[9], double Rout[9]);
 
 }  // namespace goicp
 #endif

@@ -16,6 +16,7 @@
 #include <vector>
 
 #include "goicp.hpp"
+#include "kabsch.hpp"
 
 namespace goicp {
 
@@ -98,62 +99,6 @@ void intro_select(float* d, size_t s, size_t e, size_t k) {
         d[s] = d[sp]; d[sp] = piv;
         if (sp < k) s = sp + 1; else if (sp > k) e = sp - 1; else return;
     }
-}
-
-// -------------------------------------------------------------------------------------------------
-// 3x3 SVD (one-sided Jacobi) -> Kabsch rotation with the reference's float determinant (jly_icp3d.hpp:283-303)
-// -------------------------------------------------------------------------------------------------
-static void mul3(const double* A, const double* B, double* Cm) {
-    for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) { double s = 0; for (int k = 0; k < 3; k++) s += A[3 * i + k] * B[3 * k + j]; Cm[3 * i + j] = s; }
-}
-
-void kabsch_rotation(const double H[9], double Rout[9]) {
-    double A[9], V[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
-    std::memcpy(A, H, sizeof A);
-    for (int sweep = 0; sweep < 60; sweep++) {
-        double off = 0;
-        for (int p = 0; p < 2; p++) for (int q = p + 1; q < 3; q++) {
-            double al = 0, be = 0, ga = 0;
-            for (int i = 0; i < 3; i++) { al += A[3 * i + p] * A[3 * i + p]; be += A[3 * i + q] * A[3 * i + q]; ga += A[3 * i + p] * A[3 * i + q]; }
-            if (ga == 0) continue;
-            off += std::fabs(ga) / std::sqrt(al * be + 1e-300);
-            const double zeta = (be - al) / (2 * ga);
-            const double t = (zeta >= 0 ? 1.0 : -1.0) / (std::fabs(zeta) + std::sqrt(1 + zeta * zeta));
-            const double cs = 1 / std::sqrt(1 + t * t), sn = cs * t;
-            for (int i = 0; i < 3; i++) {
-                const double ap = A[3 * i + p], aq = A[3 * i + q]; A[3 * i + p] = cs * ap - sn * aq; A[3 * i + q] = sn * ap + cs * aq;
-                const double vp = V[3 * i + p], vq = V[3 * i + q]; V[3 * i + p] = cs * vp - sn * vq; V[3 * i + q] = sn * vp + cs * vq;
-            }
-        }
-        if (off < 1e-15) break;
-    }
-    double w[3]; int ord[3] = {0, 1, 2};
-    for (int j = 0; j < 3; j++) w[j] = std::sqrt(A[j] * A[j] + A[3 + j] * A[3 + j] + A[6 + j] * A[6 + j]);
-    for (int a = 0; a < 2; a++) for (int b = a + 1; b < 3; b++) if (w[ord[b]] > w[ord[a]]) std::swap(ord[a], ord[b]);
-    double U[9], Vs[9], W[3];
-    for (int j = 0; j < 3; j++) {
-        const int s = ord[j]; W[j] = w[s];
-        for (int i = 0; i < 3; i++) { Vs[3 * i + j] = V[3 * i + s]; U[3 * i + j] = w[s] > 0 ? A[3 * i + s] / w[s] : 0; }
-    }
-    if (!(W[2] > 1e-300 * (W[0] + 1))) {      // rank-deficient H: complete U to an orthonormal basis
-        if (!(W[1] > 1e-300 * (W[0] + 1))) {
-            double a0 = U[0], a1 = U[3], a2 = U[6];
-            if (a0 * a0 + a1 * a1 + a2 * a2 == 0) { U[0] = 1; U[3] = 0; U[6] = 0; a0 = 1; a1 = a2 = 0; }
-            double bx = std::fabs(a0) < 0.9 ? 1 : 0, by = std::fabs(a0) < 0.9 ? 0 : 1, bz = 0;
-            const double dp = bx * a0 + by * a1 + bz * a2; bx -= dp * a0; by -= dp * a1; bz -= dp * a2;
-            const double nb = std::sqrt(bx * bx + by * by + bz * bz); U[1] = bx / nb; U[4] = by / nb; U[7] = bz / nb;
-        }
-        U[2] = U[3] * U[7] - U[6] * U[4]; U[5] = U[6] * U[1] - U[0] * U[7]; U[8] = U[0] * U[4] - U[3] * U[1];
-    }
-    double Ut[9], R0[9], D[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1}, VD[9];
-    for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) Ut[3 * i + j] = U[3 * j + i];
-    mul3(Vs, Ut, R0);
-    const float a = (float)(R0[0] * (R0[4] * R0[8] - R0[5] * R0[7]));
-    const float b = (float)(-R0[1] * (R0[3] * R0[8] - R0[5] * R0[6]));
-    const float c = (float)(R0[2] * (R0[3] * R0[7] - R0[4] * R0[6]));
-    const float det = a + b + c;
-    D[8] = det;
-    mul3(Vs, D, VD); mul3(VD, Ut, Rout);
 }
 
 // -------------------------------------------------------------------------------------------------
@@ -335,6 +280,7 @@ void GoICP::neighborsWeights() {
 // reference jly_goicp.cpp:180-267, then the tables are staged to the device
 void GoICP::Initialize() {
     Clear();
+    { const char* e = getenv("GOICP_DEVICE_ICP"); if (e) device_icp = atoi(e) != 0; }      // A/B knob, read once per registration
     status = GOICP_OK; error_message.clear();
     normData_.resize(Nd);
     for (int i = 0; i < Nd; i++) normData_[i] = std::sqrt(pData[i].x * pData[i].x + pData[i].y * pData[i].y + pData[i].z * pData[i].z);
@@ -420,7 +366,28 @@ float GoICP::icp_run(Matrix& R, Matrix& t) {
     for (int i = 0; i < 3; i++) { for (int j = 0; j < 3; j++) Rd[3 * i + j] = R.val[i][j]; td[i] = t.val[i][0]; }
     float err = -1, err_new = 0;
     stats.icp_calls++;
-    for (size_t iter = 0; iter < 10000; iter++) {
+    size_t iter = 0;
+    bool finished = false;
+    if (!doTrim && device_icp) {
+        // cavity-sized untrimmed clouds: the whole loop in one launch (k_icp_loop: same sums in the same order, same 3x3 algebra). It hands
+        // back early only at an iteration with an exact distance tie between model points, which the kd-tree order below decides.
+        goicp_icp_state S;
+        std::memcpy(S.R, Rd, sizeof Rd); std::memcpy(S.t, td, sizeof td);
+        for (int k = 0; k < 3; k++) { S.mu_m[k] = 0; S.mu_d[k] = 0; }
+        S.err = err; S.err_new = err_new; S.iters = 0; S.status = 0;
+        const int rc = goicp_engine_icp_loop(eng_, &S, err_diff, 10000, ids.data(), dsq.data());
+        if (rc == GOICP_OK) {
+            stats.icp_iters += (uint64_t)S.iters; iter = (size_t)S.iters;
+            std::memcpy(Rd, S.R, sizeof Rd); std::memcpy(td, S.t, sizeof td);
+            for (int k = 0; k < 3; k++) { mu_m[k] = S.mu_m[k]; mu_d[k] = S.mu_d[k]; }
+            err = S.err; err_new = S.err_new;
+            if (S.status != 1) {
+                for (int i = 0; i < n; i++) { pts[i].dis = dsq[i]; pts[i].id_data = i; pts[i].id_model = ids[i]; }
+                finished = true;
+            }
+        } else if (rc != GOICP_ERR_ARG) { status = rc; return std::numeric_limits<float>::quiet_NaN(); }
+    }
+    for (; !finished && iter < 10000; iter++) {
         stats.icp_iters++;
         const float r00 = (float)Rd[0], r01 = (float)Rd[1], r02 = (float)Rd[2], r10 = (float)Rd[3], r11 = (float)Rd[4], r12 = (float)Rd[5];
         const float r20 = (float)Rd[6], r21 = (float)Rd[7], r22 = (float)Rd[8], t0 = (float)td[0], t1 = (float)td[1], t2 = (float)td[2];

@@ -149,6 +149,17 @@ int goicp_engine_icp_nn(goicp_engine* h, const double* R9, const double* t3, int
  * restatement of that visiting order (csrc/host_kdorder.hpp). */
 int goicp_engine_icp_nn_ties(goicp_engine* h, const double* R9, const double* t3, int32_t* id_model, float* dist_sq, int32_t* n_tied);
 
+/* ICP3D<float>::Run (reference jly_icp3d.hpp:197-311) as one launch, for untrimmed clouds of at most 1024 data / 2048 model points:
+ * iterates from `state` (pose R, t; the running centroids mu_m, mu_d that the reference never resets; err = the previous
+ * iteration's error sum, -1 before the first; iters = iterations done so far) until the reference's stop test fires (status 0: R, t are
+ * the pose BEFORE the last correspondence search, err_new its error sum, id_model / dist_sq its correspondences), max_iters is
+ * reached (status 2), or an iteration meets an exact distance tie between model points (status 1: the state is the one before that
+ * iteration; the caller decides the tie in the reference's kd-tree order and carries on). Sums whose order matters are taken
+ * sequentially over the point index, the 3x3 algebra is the host's (kabsch.hpp): same bits as the host loop.
+ * GOICP_ERR_ARG when the configuration is outside the above (the caller then iterates with goicp_engine_icp_nn_ties). */
+typedef struct { double R[9], t[3], mu_m[3], mu_d[3]; float err, err_new; int32_t iters, status; } goicp_icp_state;
+int goicp_engine_icp_loop(goicp_engine* h, goicp_icp_state* state, float err_diff, int max_iters, int32_t* id_model, float* dist_sq);
+
 int goicp_engine_synchronize(goicp_engine* h);
 /* cumulative counters since create: cube evaluations, point lookups, kernel milliseconds (HIP events) */
 int goicp_engine_stats(const goicp_engine* h, uint64_t* cube_evals, uint64_t* lookups, double* kernel_ms);
