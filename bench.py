@@ -178,11 +178,12 @@ def main():
     checksum = float(ub.double().sum().item() + lb.double().sum().item())
     assert np.isfinite(checksum)
     kname = eng.eval_kernel_name()
+    fused = eng.last_eval_fused()
     # The launch group holds every rotation twice (rho = 0 and rho = maxRotDis[3], as OuterBnB's ub / lb calls do), and the engine
     # evaluates such pairs from ONE pass of gathers (k_eval_cubes_geo<.., true>). For transparency the same launch group is also timed
     # with the fusion switched off (a second engine on the same grid): reported beside the line, never as `value`.
     unfused = None
-    if kname.endswith("true>") and rank == 0:
+    if fused and rank == 0:
         os.environ["GOICP_FUSE"] = "0"
         try:
             g.initialize(); eng_u = g.engine()
@@ -272,7 +273,7 @@ def main():
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": PEAK_HBM_GBPS, "unit": "GB/s", "frac": achieved / PEAK_HBM_GBPS, "traffic": traffic,
                          "traffic_source": traffic_source, "kernel": kname, "avg_launch_ms": kern_ms, "algorithmic_bytes_per_launch": bytes_per_launch,
                          "point_lookups_per_sec": value / world * nd,
-                         "fused_group_pairs": kname.endswith("true>"), "unfused": unfused},
+                         "fused_group_pairs": fused, "unfused": unfused},
             "cpu_baseline": cpu,
             "registration": reg,
             "cavity_batch": cav,

@@ -221,6 +221,10 @@ class Engine:
     def eval_kernel_name(self):
         return self.L.goicp_engine_eval_kernel_name(self.h).decode()
 
+    def last_eval_fused(self):
+        """True if the last multi-group sweep evaluated its (no radius, radius) group pairs from one pass of gathers."""
+        return bool(self.L.goicp_engine_last_eval_fused(self.h))
+
     def stats(self):
         ce = C.c_uint64(); lk = C.c_uint64(); ms = C.c_double()
         self.L.goicp_engine_stats(self.h, C.byref(ce), C.byref(lk), C.byref(ms))

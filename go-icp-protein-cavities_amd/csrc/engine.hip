@@ -163,6 +163,10 @@ __global__ void k_fpfh_table(DevTables T, float* __restrict__ E) {
     E[k] = minD;
 }
 
+__device__ __forceinline__ double cube_sum(double v) {       // over the 8 lanes of a wave that hold the same (lane & 7)
+    v += __shfl_xor(v, 8, 64); v += __shfl_xor(v, 16, 64); v += __shfl_xor(v, 32, 64);
+    return v;
+}
 __device__ __forceinline__ double wave_sum(double v) {
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
@@ -1056,12 +1060,91 @@ __device__ __forceinline__ void heap_pop_wave(const HeapStoreT<N>& a, int& n, in
 // (ub, lb per cube) in part_out instead of finishing the bounds -- one node's sweep split over several workgroups (k_fr_expand).
 template <bool OCT, int BLOCK = 1024, bool PARTIAL = false>
 __device__ __forceinline__ void sweep_stream(const DevTables& T, TileShm<BLOCK>& sh, const float4* __restrict__ rot, const float* __restrict__ rho_row,
-                                             float* __restrict__ rows, int NdP, int p0 = 0, int p1 = 0, double* __restrict__ part_out = nullptr) {
+                                             float* __restrict__ rows, int NdP, int p0 = 0, int p1 = 0, double* __restrict__ part_out = nullptr,
+                                             const float* __restrict__ dual_rho = nullptr /* untrimmed, !PARTIAL: second call's radius row (see sweep_tile DUAL) */) {
     const int tid = threadIdx.x, wv = tid >> 6, ln = tid & 63;
     const int Nd = PARTIAL ? p1 : T.Nd, S = T.S;
     const bool row_mode = !OCT && sh.ctl[2];
     const bool sq = T.norm == 2, lin = T.norm == 1;
     const bool trim = !PARTIAL && T.doTrim != 0;
+    if (!trim) {
+        // Untrimmed runs keep nothing per point, so the sweep runs with lane = (point, cube): lane l adds up cube l & 7 over the points
+        // (l >> 3) + BLOCK/8 * k. The 8 lanes of a point read cells of nearby grid rows / one row, i.e. 8-32 cache lines per wave instruction
+        // instead of 64 unrelated ones -- the vector L1 works through the lines of an instruction one by one (tools/gather_modes.py: the same
+        // lookups in 1.85 ms instead of 3.77 ms on the configs[2] tiles). Two fp64 accumulators per lane, 8 lookups in flight.
+        constexpr int PB = BLOCK / 8, U = 8;
+        const int j = tid & 7, q = tid >> 3;
+        const float cx = sh.cen[j][0], cy = sh.cen[j][1], cz = sh.cen[j][2], mtd = sh.mtd[j];
+        double su1 = 0.0, sl1 = 0.0, su2 = 0.0, sl2 = 0.0;        // (su2, sl2: the second call of a fused pair -- same lookups, radius dual_rho)
+        for (int b = (PARTIAL ? p0 : 0); b < Nd; b += PB * U) {
+            unsigned idx[U]; float w[U], rh[U], rh2[U], ext[U]; bool valid[U];
+#pragma unroll
+            for (int k = 0; k < U; k++) {
+                const int i = b + q + k * PB;
+                valid[k] = i < Nd;
+                const float4 p = rot[min(i, Nd - 1)];
+                rh[k] = rho_row ? rho_row[min(i, Nd - 1)] : 0.f;
+                rh2[k] = dual_rho ? dual_rho[min(i, Nd - 1)] : 0.f;
+                const int x = cell_of(p.x + cx, T.xMin, T.scale), y = cell_of(p.y + cy, T.yMin, T.scale), z = cell_of(p.z + cz, T.zMin, T.scale);
+                idx[k] = (unsigned)((clamp_cell(z, S) * S + clamp_cell(y, S)) * S + clamp_cell(x, S));
+                ext[k] = dt_ext_raw(x, y, z, S);
+                w[k] = p.w;
+            }
+            float v[U];
+            if (T.code) {
+                unsigned c[U];
+#pragma unroll
+                for (int k = 0; k < U; k++) c[k] = T.code[idx[k]];
+#pragma unroll
+                for (int k = 0; k < U; k++) v[k] = dt_decode(T, idx[k], c[k], nullptr);
+            } else {
+#pragma unroll
+                for (int k = 0; k < U; k++) v[k] = T.dist[idx[k]];
+            }
+#pragma unroll
+            for (int k = 0; k < U; k++) {
+                float d = w[k] * dt_finish(T, v[k], ext[k]);
+                if (rho_row) d -= rh[k];
+                if (d < 0.f) d = 0.f;
+                const float e = d - mtd;
+                const float tu = sq ? d * d : (lin ? d : 0.f);
+                const float tl = sq ? e * e : (lin ? e : 0.f);
+                if (valid[k]) { su1 += (double)tu; if (e > 0.f) sl1 += (double)tl; }
+                if (dual_rho) {                               // minDis -= maxRotDisL; clamp (reference jly_goicp.cpp:375-381) on the same product
+                    float d2 = d - rh2[k];
+                    if (d2 < 0.f) d2 = 0.f;
+                    const float e2 = d2 - mtd;
+                    const float tu2 = sq ? d2 * d2 : (lin ? d2 : 0.f);
+                    const float tl2 = sq ? e2 * e2 : (lin ? e2 : 0.f);
+                    if (valid[k]) { su2 += (double)tu2; if (e2 > 0.f) sl2 += (double)tl2; }
+                }
+            }
+        }
+        if (dual_rho) {
+            // first call of the pair -> sh.ub2 / sh.lb2 (one more trip through the per-wave partials)
+            su1 = cube_sum(su1); sl1 = cube_sum(sl1);
+            if (ln < TC) { sh.red[wv][2 * ln] = su1; sh.red[wv][2 * ln + 1] = sl1; }
+            __syncthreads();
+            if (tid < TC) {
+                double u = 0.0, l = 0.0;
+                for (int w2 = 0; w2 < BLOCK / 64; w2++) { u += sh.red[w2][2 * tid]; l += sh.red[w2][2 * tid + 1]; }
+                sh.ub2[tid] = (float)u; sh.lb2[tid] = (float)l;
+            }
+            __syncthreads();
+            su1 = su2; sl1 = sl2;
+        }
+        su1 = cube_sum(su1); sl1 = cube_sum(sl1);
+        if (ln < TC) { sh.red[wv][2 * ln] = su1; sh.red[wv][2 * ln + 1] = sl1; }
+        __syncthreads();
+        if (tid < TC) {
+            double u = 0.0, l = 0.0;
+            for (int w2 = 0; w2 < BLOCK / 64; w2++) { u += sh.red[w2][2 * tid]; l += sh.red[w2][2 * tid + 1]; }
+            if (PARTIAL) { part_out[2 * tid] = u; part_out[2 * tid + 1] = l; }
+            else { sh.ub[tid] = (float)u; sh.lb[tid] = (float)l; }
+        }
+        __syncthreads();
+        return;
+    }
     double su[TC], sl[TC]; unsigned mx[TC];
 #pragma unroll
     for (int j = 0; j < TC; j++) { su[j] = 0.0; sl[j] = 0.0; mx[j] = 0u; }
@@ -1804,17 +1887,19 @@ __global__ __launch_bounds__(BLOCK, (MODE == 0 ? 4 : (BLOCK == 512 ? 4 : 1))) vo
 template <int BLOCK>
 __global__ __launch_bounds__(BLOCK, (BLOCK == 512 ? 4 : 1)) void k_eval_cubes_stream(DevTables T, const float4* __restrict__ rot_all, int slot0, int level0,
                                                             const int2* __restrict__ groups, int ngroups, const float* __restrict__ cubes, int n,
-                                                            float* __restrict__ ub_out, float* __restrict__ lb_out) {
+                                                            float* __restrict__ ub_out, float* __restrict__ lb_out,
+                                                            const int4* __restrict__ pairs /* untrimmed runs: fused (no radius, radius) group pairs as in k_eval_cubes_geo, or null */) {
     __shared__ TileShm<BLOCK> sh;
     const int tid = threadIdx.x;
     const int Nd = T.Nd;
     float* rows = T.srows ? T.srows + (size_t)blockIdx.x * TC * T.NdP : nullptr;
     const int tiles = (n + TC - 1) / TC;
-    const long long total = (long long)tiles * ngroups;
+    const long long total = (long long)tiles * ngroups;            // (ngroups = number of pairs when `pairs` is given)
     for (long long w = blockIdx.x; w < total; w += gridDim.x) {
         const int g = (int)(w / tiles), base = (int)(w % tiles) * TC;
-        int slot = slot0, rot_level = level0;
-        if (groups) { const int2 gg = groups[g]; slot = gg.x; rot_level = gg.y; }
+        int slot = slot0, rot_level = level0, row_a = g, row_b = g;
+        if (pairs) { const int4 pp = pairs[g]; slot = pp.x; rot_level = pp.y; row_a = pp.z; row_b = pp.w; }
+        else if (groups) { const int2 gg = groups[g]; slot = gg.x; rot_level = gg.y; }
         if (tid < TC) {
             const int j = tid, c = min(base + j, n - 1);
             const float x = cubes[4 * c], y = cubes[4 * c + 1], z = cubes[4 * c + 2], wd = cubes[4 * c + 3];
@@ -1829,8 +1914,16 @@ __global__ __launch_bounds__(BLOCK, (BLOCK == 512 ? 4 : 1)) void k_eval_cubes_st
             sh.ctl[2] = row ? 1 : 0;
         }
         __syncthreads();
-        sweep_stream<false, BLOCK>(T, sh, rot_all + (size_t)slot * Nd, rot_level >= 0 ? T.maxRotDis + (size_t)rot_level * Nd : nullptr, rows, T.NdP);
-        if (tid < TC && base + tid < n) { ub_out[(size_t)g * n + base + tid] = sh.ub[tid]; lb_out[(size_t)g * n + base + tid] = sh.lb[tid]; }
+        if (pairs) {
+            sweep_stream<false, BLOCK>(T, sh, rot_all + (size_t)slot * Nd, nullptr, rows, T.NdP, 0, 0, nullptr, T.maxRotDis + (size_t)rot_level * Nd);
+            if (tid < TC && base + tid < n) {
+                ub_out[(size_t)row_a * n + base + tid] = sh.ub2[tid]; lb_out[(size_t)row_a * n + base + tid] = sh.lb2[tid];
+                ub_out[(size_t)row_b * n + base + tid] = sh.ub[tid];  lb_out[(size_t)row_b * n + base + tid] = sh.lb[tid];
+            }
+        } else {
+            sweep_stream<false, BLOCK>(T, sh, rot_all + (size_t)slot * Nd, rot_level >= 0 ? T.maxRotDis + (size_t)rot_level * Nd : nullptr, rows, T.NdP);
+            if (tid < TC && base + tid < n) { ub_out[(size_t)g * n + base + tid] = sh.ub[tid]; lb_out[(size_t)g * n + base + tid] = sh.lb[tid]; }
+        }
         __syncthreads();
     }
 }
@@ -2324,6 +2417,7 @@ struct goicp_engine {
     int streamed; size_t stream_wgs, stream_rot_wgs;   // streaming path: scratch sized for this many resident workgroups (rows / rotated clouds)
     int eval_pad;                            // extra dynamic LDS bytes of the just-in-time sweep kernel (experiment knob GOICP_EVAL_PAD: 16384 leaves one workgroup per CU)
     int eval_nt;                             // cubes per workgroup tile of the just-in-time sweep kernel (experiment knob GOICP_EVAL_NT: 8, 4 or 2)
+    int last_fused;                          // the last goicp_engine_eval_cubes* call evaluated its (no radius, radius) group pairs from one pass of gathers
     int xcd_mode;                            // workgroup -> (group, tile) map of k_eval_cubes_geo (GOICP_XCD, read once per engine)
     int jit_eval;                            // clouds of 1025..5120 points without penalty terms: the just-in-time sweep kernels (GOICP_JIT=0 disables; read once per engine)
     int jit_bnb;                             // geometric searches of 1025..2048 points: k_inner_bnb<512, 4, false, false, true>
@@ -2619,7 +2713,7 @@ extern "C" int goicp_engine_create(const goicp_engine_desc* d, goicp_engine** ou
     h->n_cubes = h->n_lookups = 0; h->kernel_ms = 0; h->max_pops = 200000000u;
     { const char* e = getenv("GOICP_EVAL_NT"); h->eval_nt = (e && (atoi(e) == 4 || atoi(e) == 2)) ? atoi(e) : 8; }
     { const char* e = getenv("GOICP_EVAL_PAD"); h->eval_pad = e ? std::max(0, std::min(atoi(e), 60000)) : 0; }
-    h->code_escapes = 0;
+    h->code_escapes = 0; h->last_fused = 0;
     h->fr_mode = 0; h->fr_st = nullptr; h->fr_heaps = nullptr; h->fr_exps = nullptr; h->fr_wl = nullptr; h->fr_cnt = nullptr; h->fr_parts = nullptr; h->fr_srot = nullptr; h->fr_results = nullptr;
     h->fr_jobs = 0; h->fr_cap_nodes = 0; h->fr_cap_exps = 0; h->fr_wl_cap = 0; h->fr_rounds = 0; h->fr_spec_cubes = 0;
 #define CR(call) do { int rc_ = (call); if (rc_ != GOICP_OK) { std::string m = h->err; goicp_engine_destroy(h); fprintf(stderr, "goicp_engine_create: %s\n", m.c_str()); return rc_; } } while (0)
@@ -2828,6 +2922,7 @@ extern "C" int goicp_engine_debug_times(goicp_engine* h, unsigned long long* out
     return GOICP_OK;
 }
 
+extern "C" int goicp_engine_last_eval_fused(const goicp_engine* h) { return h ? h->last_fused : 0; }
 extern "C" int goicp_engine_num_slots(const goicp_engine* h) { return h ? h->nslots : 0; }
 extern "C" int goicp_engine_resident_jobs(const goicp_engine* h) { return h ? h->resident_jobs : 0; }
 extern "C" void* goicp_engine_stream(const goicp_engine* h) { return h ? (void*)h->stream : nullptr; }
@@ -2893,18 +2988,24 @@ static int ensure_stream_scratch(goicp_engine* h, size_t wgs, bool need_rot, boo
 
 static int launch_eval(goicp_engine* h, int slot, int rot_level, const int2* groups_dev, int ngroups, const void* cubes_dev, int n, void* ub_dev, void* lb_dev) {
     if (h->streamed) {
-        const long long total = (long long)((n + TC - 1) / TC) * ngroups;
+        // untrimmed runs: group pairs (no radius / radius, same slot) of a multi-group call are evaluated from one pass of gathers when all pair up
+        const bool dual = !h->T.doTrim && groups_dev == h->d_groups && h->npairs > 0 && h->npairs * 2 == ngroups;
+        const int ng = dual ? h->npairs : ngroups;
+        const int4* ptab = dual ? h->d_pairs : nullptr;
+        h->last_fused = dual ? 1 : 0;
+        const long long total = (long long)((n + TC - 1) / TC) * ng;
         const int wgs = (int)std::min<long long>(total, 1024);         // persistent workgroups: a few per CU (two 512-lane ones are resident)
         int rcs = ensure_stream_scratch(h, (size_t)wgs, false);
         if (rcs != GOICP_OK) return rcs;
         // two 512-lane workgroups per CU overlap gathering and selection (+12 % at 6 000 points); from 16 K points on the sweep is
         // bound by the row and grid traffic itself and the 1024-lane form is as fast or faster
-        if (h->T.Nd > 16384) hipLaunchKernelGGL(k_eval_cubes_stream<1024>, dim3(wgs), dim3(1024), 0, h->stream, h->T, h->d_rot, slot, rot_level, groups_dev, ngroups, (const float*)cubes_dev, n, (float*)ub_dev, (float*)lb_dev);
-        else hipLaunchKernelGGL(k_eval_cubes_stream<512>, dim3(wgs), dim3(512), 0, h->stream, h->T, h->d_rot, slot, rot_level, groups_dev, ngroups, (const float*)cubes_dev, n, (float*)ub_dev, (float*)lb_dev);
+        if (h->T.Nd > 16384) hipLaunchKernelGGL(k_eval_cubes_stream<1024>, dim3(wgs), dim3(1024), 0, h->stream, h->T, h->d_rot, slot, rot_level, groups_dev, ng, (const float*)cubes_dev, n, (float*)ub_dev, (float*)lb_dev, ptab);
+        else hipLaunchKernelGGL(k_eval_cubes_stream<512>, dim3(wgs), dim3(512), 0, h->stream, h->T, h->d_rot, slot, rot_level, groups_dev, ng, (const float*)cubes_dev, n, (float*)ub_dev, (float*)lb_dev, ptab);
         HIPCHK(h, hipGetLastError());
         h->n_cubes += (uint64_t)n * ngroups; h->n_lookups += (uint64_t)n * ngroups * h->T.Nd;
         return GOICP_OK;
     }
+    h->last_fused = 0;
     const int tiles = (n + TC - 1) / TC;
     int rc = ensure_fpscratch(h, (size_t)tiles * ngroups);
     if (rc != GOICP_OK) return rc;
@@ -2916,6 +3017,7 @@ static int launch_eval(goicp_engine* h, int slot, int rot_level, const int2* gro
     if (jit && h->eval_nt == 8) {
         // geometric just-in-time sweep: its own kernel; group pairs (no radius / radius, same slot) of a multi-group call fused when all pair up
         const bool dual = groups_dev == h->d_groups && h->npairs > 0 && h->npairs * 2 == ngroups;
+        h->last_fused = dual ? 1 : 0;
         const int4* gtab = h->d_pairs;
         if (!dual) {
             // (single-group calls and unpaired tables: one int4 per group, staged here; the table of a repeated multi-group call is cached)

@@ -169,6 +169,9 @@ int goicp_engine_search_stats(const goicp_engine* h, uint64_t* rounds, uint64_t*
 /* diagnosis: run ONLY the distance-grid gathers of the last goicp_engine_eval_cubes_multi_dev launch shape (same grid, clouds, cubes, cell
  * arithmetic; nothing kept) and report the kernel time -- the memory-system floor of the sweep's access pattern. scratch_dev: >= n/8 floats. */
 int goicp_engine_debug_gather_probe(goicp_engine* h, const void* cubes_dev, int n, void* scratch_dev, int variant, float* ms_out);
+/* 1 if the last goicp_engine_eval_cubes_multi_dev call evaluated its (rot_level -1, rot_level >= 0) group pairs of one slot from ONE pass of
+ * gathers (fused sweep: OuterBnB's ub / lb calls of a rotation read the same DT cells, reference jly_goicp.cpp:768,861), else 0 */
+int goicp_engine_last_eval_fused(const goicp_engine* h);
 /* name of the cube-sweep kernel instantiation goicp_engine_eval_cubes* launches for this handle (as profilers print it) */
 const char* goicp_engine_eval_kernel_name(goicp_engine* h);
 /* opaque hipStream_t of the handle, for callers that time with their own HIP events */

@@ -401,7 +401,7 @@ def test_multi_group_launch_equals_single_launches():
     e.close()
 
 
-@pytest.mark.parametrize("n,trim", [(5000, 0.1), (3000, 0.0), (1500, 0.1)])
+@pytest.mark.parametrize("n,trim", [(5000, 0.1), (3000, 0.0), (1500, 0.1), (9000, 0.0), (20000, 0.0)])
 def test_fused_group_pairs_equal_separate_launches(n, trim, monkeypatch):
     """Clouds of 1025..5120 points, geometric error: a multi-group launch whose groups pair up (same rotation slot, one call without
     rotation uncertainty and one with -- OuterBnB's ub / lb calls, jly_goicp.cpp:768,861) is evaluated from ONE pass of gathers
@@ -432,14 +432,16 @@ def test_fused_group_pairs_equal_separate_launches(n, trim, monkeypatch):
         e = engine()
         for s_, R in enumerate(Rs):
             e.set_rotation(s_, R)
-        assert e.eval_kernel_name().startswith("k_eval_cubes_geo")
+        assert e.eval_kernel_name().startswith("k_eval_cubes_geo" if n <= 5120 else "k_eval_cubes_stream")      # (untrimmed streamed clouds fuse pairs too)
         for tag, slots, levels in (("paired", [0, 1, 0, 2, 1, 2], [-1, 4, 3, -1, -1, 0]), ("unpaired", [0, 1, 1], [-1, -1, 2])):
             ub = torch.zeros((len(slots), nc), device="cuda"); lb = torch.zeros_like(ub)
             e.eval_cubes_multi_dev(np.array(slots, np.int32), np.array(levels, np.int32), dc.data_ptr(), nc, ub.data_ptr(), lb.data_ptr())
             e.synchronize()
             outs[(fuse, tag)] = (ub.cpu().numpy(), lb.cpu().numpy())
             if fuse == "1":
-                assert e.eval_kernel_name().endswith("true>" if tag == "paired" else "false>")
+                assert e.last_eval_fused() == (tag == "paired")
+                if n <= 5120:
+                    assert e.eval_kernel_name().endswith("true>" if tag == "paired" else "false>")
                 for g_, (sl, lv) in enumerate(zip(slots, levels)):
                     u1, l1 = e.eval_cubes(sl, lv, cubes)
                     assert np.array_equal(outs[(fuse, tag)][0][g_], u1) and np.array_equal(outs[(fuse, tag)][1][g_], l1)
