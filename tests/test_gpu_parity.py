@@ -432,7 +432,8 @@ def test_fused_group_pairs_equal_separate_launches(n, trim, monkeypatch):
         e = engine()
         for s_, R in enumerate(Rs):
             e.set_rotation(s_, R)
-        assert e.eval_kernel_name().startswith("k_eval_cubes_geo" if n <= 5120 else "k_eval_cubes_stream")      # (untrimmed streamed clouds fuse pairs too)
+        geo = n <= 5120                       # (above that the streamed sweep; untrimmed streamed runs fuse pairs too)
+        assert e.eval_kernel_name().startswith("k_eval_cubes_geo" if geo else "k_eval_cubes_stream")
         for tag, slots, levels in (("paired", [0, 1, 0, 2, 1, 2], [-1, 4, 3, -1, -1, 0]), ("unpaired", [0, 1, 1], [-1, -1, 2])):
             ub = torch.zeros((len(slots), nc), device="cuda"); lb = torch.zeros_like(ub)
             e.eval_cubes_multi_dev(np.array(slots, np.int32), np.array(levels, np.int32), dc.data_ptr(), nc, ub.data_ptr(), lb.data_ptr())
@@ -440,7 +441,7 @@ def test_fused_group_pairs_equal_separate_launches(n, trim, monkeypatch):
             outs[(fuse, tag)] = (ub.cpu().numpy(), lb.cpu().numpy())
             if fuse == "1":
                 assert e.last_eval_fused() == (tag == "paired")
-                if n <= 5120:
+                if geo:
                     assert e.eval_kernel_name().endswith("true>" if tag == "paired" else "false>")
                 for g_, (sl, lv) in enumerate(zip(slots, levels)):
                     u1, l1 = e.eval_cubes(sl, lv, cubes)
