@@ -61,6 +61,8 @@ struct DevTables {
     int Nd, Nm, inlierNum, doTrim, norm, b0, b1;
     float reg, regFPFH;
     int use_compat, use_fpfh, exact;
+    int exact_big;           // parity_mode 2, 1025..5120 points, geometric error: reference-order sums / intro_select on residual rows in HBM (xrows)
+    float* xrows; int xslots; // [xslots][2 * TC * NdP] floats: addend / residual rows + selection scratch of one workgroup each
     float4* srot;            // streaming path (Nd > 8192): per-workgroup rotated cloud [NdP]
     float* srows;            // streaming path, trimmed runs: per-workgroup residual rows [TC][NdP]
     int NdP;                 // row pitch of the two above
@@ -230,6 +232,14 @@ __device__ __forceinline__ void wave_sync_lds() {
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
+// the same hand-off between the lanes of a wave when the data may live in HBM (rows of parity_mode 2): workgroup scope makes the compiler wait for the
+// outstanding vector-memory operations as well (a CU's waves share its L1, so nothing has to be written back or invalidated)
+__device__ __forceinline__ void wave_sync_mem() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+}
+template <bool MEM = false>
 __device__ __forceinline__ void wave_intro_select(float* d, int* idx, int n, int k, int lane) {
     int s = 0, e = n - 1;
     int prev = e - s + 1, tries = 0; bool quick = true;
@@ -245,13 +255,13 @@ __device__ __forceinline__ void wave_intro_select(float* d, int* idx, int n, int
         else {
             int tmp = 0;
             if (lane == 0) tmp = sel_median_of_medians(d, s, e);       // rare fallback: one lane, the reference's in-place group medians
-            wave_sync_lds();
+            (MEM ? wave_sync_mem() : wave_sync_lds());
             pi = __shfl(tmp, 0, 64);
         }
         const float piv = d[pi];
-        wave_sync_lds();
+        (MEM ? wave_sync_mem() : wave_sync_lds());
         if (pi != s && lane == 0) { d[pi] = d[s]; d[s] = piv; }
-        wave_sync_lds();
+        (MEM ? wave_sync_mem() : wave_sync_lds());
         // lane l owns the contiguous chunk [b0, b1) of (s, e]
         const int L = e - s;                                           // elements besides the pivot
         const int c = (L + 63) / 64;
@@ -270,7 +280,7 @@ __device__ __forceinline__ void wave_intro_select(float* d, int* idx, int n, int
         // idx[i] = position of the i-th '>' from the left; idx[L-1-i] = position of the i-th '<' from the right (nG + nLt <= L)
         { int rg = pg; for (int p = b0; p < b1; p++) if (d[p] > piv) idx[rg++] = p; }
         { int rl = pl; for (int p = b1 - 1; p >= b0; p--) if (d[p] < piv) idx[L - 1 - (rl++)] = p; }
-        wave_sync_lds();
+        (MEM ? wave_sync_mem() : wave_sync_lds());
         // pair i is swapped iff its two members have not crossed; pairs are disjoint, so one lane per pair is race-free
         int t = 0;
         for (int i = lane, m = min(nG, nLt); i < m; i += 64) {
@@ -279,7 +289,7 @@ __device__ __forceinline__ void wave_intro_select(float* d, int* idx, int n, int
         }
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) t += __shfl_xor(t, off, 64);
-        wave_sync_lds();
+        (MEM ? wave_sync_mem() : wave_sync_lds());
         // where the reference's scan pointers end up, and where the pivot comes to rest (jly_sorting.hpp:282-303)
         const int hi0 = t > 0 ? idx[L - 1 - (t - 1)] : e;
         int lo1 = hi0; bool lo_is_greater;
@@ -287,10 +297,10 @@ __device__ __forceinline__ void wave_intro_select(float* d, int* idx, int n, int
         else lo_is_greater = t > 0 ? true : !(d[e] < piv);            // t == 0: d[e] is untouched; '<' means the pivot swaps with it
         const int sp = lo_is_greater ? lo1 - 1 : lo1;
         if (lane == 0) { d[s] = d[sp]; d[sp] = piv; }
-        wave_sync_lds();
+        (MEM ? wave_sync_mem() : wave_sync_lds());
         if (sp < k) s = sp + 1; else if (sp > k) e = sp - 1; else break;
     }
-    wave_sync_lds();
+    (MEM ? wave_sync_mem() : wave_sync_lds());
 }
 
 template <int BLOCK>
@@ -429,7 +439,7 @@ __device__ __forceinline__ void sweep_tile(const DevTables& T, TileShm<BLOCK>& s
     // everything behind the gathers (selection + sums -> sh.ub / sh.lb) as one block, so that the fused form can run it twice on the same
     // distance values: first for the call without rotation uncertainty, then again after subtracting the radius of the other call
     auto finish = [&]() __attribute__((always_inline)) {      // (out of line the residual registers would go through scratch memory)
-    if (BLOCK * PPT <= 1024 && T.exact && T.doTrim) {
+    if ((BLOCK * PPT <= 1024 || JIT) && (JIT ? T.exact_big : T.exact) && T.doTrim) {
         // parity mode, trimmed: residual rows to LDS, one lane per cube runs the reference's selection (same swaps, same final
         // order), then the inlier sums are taken sequentially in float over that order -- bit-exact with jly_goicp.cpp:384-415
 #pragma unroll
@@ -442,7 +452,7 @@ __device__ __forceinline__ void sweep_tile(const DevTables& T, TileShm<BLOCK>& s
         }
         __syncthreads();
         for (int j = tid >> 6; j < NT; j += BLOCK / 64)
-            wave_intro_select(rbuf + j * Nd, reinterpret_cast<int*>(rbuf + NT * Nd) + j * Nd, Nd, T.inlierNum - 1, tid & 63);
+            wave_intro_select<JIT>(rbuf + j * Nd, reinterpret_cast<int*>(rbuf + NT * Nd) + j * Nd, Nd, T.inlierNum - 1, tid & 63);      // (JIT: rows in HBM)
         __syncthreads();
         if (tid < 2 * NT) {
             const int j = tid & (NT - 1);
@@ -471,7 +481,7 @@ __device__ __forceinline__ void sweep_tile(const DevTables& T, TileShm<BLOCK>& s
         __syncthreads();
         return;
     }
-    if (T.exact && !T.doTrim) {
+    if ((JIT ? T.exact_big : T.exact) && !T.doTrim) {
         // reference order: float, sequential over the point index (bit-exact with jly_goicp.cpp:393-415). Every lane first
         // turns its residuals into the two addends (d*d and max(d-mtd,0)^2, or the norm-1 forms) in parallel; 16 lanes then
         // run the 16 sequential float sums (8 ub chains, 8 lb chains), one add per element. Skipping a term (e <= 0) and
@@ -642,10 +652,10 @@ __device__ __forceinline__ void sweep_tile(const DevTables& T, TileShm<BLOCK>& s
                     }
                     const int less = __popcll(__ballot(v0 && c0 < pre)) + __popcll(__ballot(v1 && c1 < pre));
                     remj -= less;                                 // rank among the copies of the threshold
-                    float fu = 0.f, fl = 0.f;
-                    if (v0 && c0 < pre) { const float d = __uint_as_float(c0), e = d - mtd; fu += T.norm == 2 ? d * d : (T.norm == 1 ? d : 0.f); if (e > 0.f) fl += T.norm == 2 ? e * e : (T.norm == 1 ? e : 0.f); }
-                    if (v1 && c1 < pre) { const float d = __uint_as_float(c1), e = d - mtd; fu += T.norm == 2 ? d * d : (T.norm == 1 ? d : 0.f); if (e > 0.f) fl += T.norm == 2 ? e * e : (T.norm == 1 ? e : 0.f); }
-                    cu = (double)fu; cl = (double)fl;
+                    // (a lane's two candidate terms are added in double: which members of the bin share a lane depends on the order of the LDS
+                    // adds that collected them, and a float sum of two terms would round differently from run to run)
+                    if (v0 && c0 < pre) { const float d = __uint_as_float(c0), e = d - mtd; cu += (double)(T.norm == 2 ? d * d : (T.norm == 1 ? d : 0.f)); if (e > 0.f) cl += (double)(T.norm == 2 ? e * e : (T.norm == 1 ? e : 0.f)); }
+                    if (v1 && c1 < pre) { const float d = __uint_as_float(c1), e = d - mtd; cu += (double)(T.norm == 2 ? d * d : (T.norm == 1 ? d : 0.f)); if (e > 0.f) cl += (double)(T.norm == 2 ? e * e : (T.norm == 1 ? e : 0.f)); }
                 }
                 // partial sums of all waves (lane w holds wave w's), plus this wave's candidate terms
                 cu += ln < NW ? sh.red[ln][2 * j] : 0.0;
@@ -1845,7 +1855,7 @@ __device__ __forceinline__ void fr_expand_item(const DevTables& T, const FrCtx& 
         float px[PPT], py[PPT], pz[PPT], pw[PPT], prho[PPT];
 #pragma unroll
         for (int m = 0; m < PPT; m++) { px[m] = py[m] = pz[m] = pw[m] = prho[m] = 0.f; }
-        sweep_tile<BLOCK, PPT, true, NT, true>(T, sh, px, py, pz, pw, prho, level >= 0, nullptr, false, rot, rho, T.code ? lutl : nullptr);
+        sweep_tile<BLOCK, PPT, true, NT, true>(T, sh, px, py, pz, pw, prho, level >= 0, rows, false, rot, rho, T.code ? lutl : nullptr);
         if (tid < NT) { out->ub[j0 + tid] = sh.ub[tid]; out->lb[j0 + tid] = sh.lb[tid]; }
         if (tid == 0 && item.split == 0) out->child_base = item.pad;
     } else if constexpr (MODE == 1) {
@@ -1862,7 +1872,7 @@ __device__ __forceinline__ void fr_expand_item(const DevTables& T, const FrCtx& 
 }
 
 template <int BLOCK, int PPT, int MODE, int NT>
-__global__ __launch_bounds__(BLOCK, (MODE == 0 ? 4 : (BLOCK == 512 ? 4 : 1))) void k_fr_expand(DevTables T, FrCtx C, int round) {
+__global__ __launch_bounds__(BLOCK, (MODE == 0 ? 4 : (BLOCK == 512 ? 4 : 1))) void k_fr_expand(DevTables T, FrCtx C, int round, int item0) {
     __shared__ TileShm<BLOCK> sh;
     __shared__ float lutl[MODE == 0 ? LUT_LDS : 1];
     const unsigned n = min(C.wl_count[round], (unsigned)C.wl_cap);
@@ -1876,7 +1886,8 @@ __global__ __launch_bounds__(BLOCK, (MODE == 0 ? 4 : (BLOCK == 512 ? 4 : 1))) vo
     } else {
         // one item per workgroup (the host sizes the grid from the number of live searches). Inside a loop the compiler hoists the
         // per-lane point addresses of all PPT fetches out of it and the residuals no longer fit the 128 registers of 2 workgroups per CU.
-        if (blockIdx.x < n) fr_expand_item<BLOCK, PPT, MODE, NT>(T, C, sh, C.wl[blockIdx.x], nullptr, lutl);
+        // (parity_mode 2: the launch goes out in chunks of T.xslots items, each workgroup with a slot of row scratch in HBM)
+        if (blockIdx.x + item0 < n) fr_expand_item<BLOCK, PPT, MODE, NT>(T, C, sh, C.wl[blockIdx.x + item0], T.exact_big ? T.xrows + (size_t)blockIdx.x * 2 * TC * T.NdP : nullptr, lutl);
     }
 }
 
@@ -2077,7 +2088,7 @@ __global__ __launch_bounds__(BLOCK) void k_gather_probe(DevTables T, const float
 template <int PPT, bool DUAL>
 __global__ __launch_bounds__(512, 4) void k_eval_cubes_geo(DevTables T, const float4* __restrict__ rot_all, const int4* __restrict__ groups,
                                                            const float* __restrict__ cubes, int n, float* __restrict__ ub_out, float* __restrict__ lb_out,
-                                                           int tiles, int ngroups, int xcd_mode) {
+                                                           int tiles, int ngroups, int xcd_mode, int lin0 /* first workgroup of this launch (chunked launches of the exact mode) */) {
     __shared__ TileShm<512> sh;
     __shared__ float lutl[LUT_LDS];
     // 1-D grid; workgroups are dealt round-robin over the 8 XCDs (each with its own 4 MB L2), so `blockIdx.x & 7` labels the workgroups
@@ -2095,8 +2106,10 @@ __global__ __launch_bounds__(512, 4) void k_eval_cubes_geo(DevTables T, const fl
             const int tper = (tiles + 7) >> 3;
             by = slot / tper; bx = lab * tper + slot % tper;
             if (by >= ngroups || bx >= tiles) return;
-        } else { if (lin >= tiles * ngroups) return; bx = lin % tiles; by = lin / tiles; }
+        } else { const int l2 = lin + lin0; if (l2 >= tiles * ngroups) return; bx = l2 % tiles; by = l2 / tiles; }
     }
+    // parity_mode 2: this workgroup's rows in HBM (the launch holds at most T.xslots workgroups)
+    float* xr = T.exact_big ? T.xrows + (size_t)blockIdx.x * 2 * TC * T.NdP : nullptr;
     const int tid = threadIdx.x, Nd = T.Nd, base = bx * TC;
     if (T.code) { for (int i = tid; i < LUT_LDS; i += 512) lutl[i] = T.lut[i]; }     // (ordered by the barrier behind the cube set-up)
     const int4 g = groups[by];
@@ -2118,13 +2131,13 @@ __global__ __launch_bounds__(512, 4) void k_eval_cubes_geo(DevTables T, const fl
 #pragma unroll
     for (int m = 0; m < PPT; m++) { px[m] = py[m] = pz[m] = pw[m] = prho[m] = 0.f; }
     if constexpr (DUAL) {
-        sweep_tile<512, PPT, false, TC, true, true>(T, sh, px, py, pz, pw, prho, false, nullptr, row, rot, nullptr, T.code ? lutl : nullptr, rho);
+        sweep_tile<512, PPT, false, TC, true, true>(T, sh, px, py, pz, pw, prho, false, xr, row, rot, nullptr, T.code ? lutl : nullptr, rho);
         if (tid < TC && base + tid < n) {
             ub_out[(size_t)g.z * n + base + tid] = sh.ub2[tid]; lb_out[(size_t)g.z * n + base + tid] = sh.lb2[tid];
             ub_out[(size_t)g.w * n + base + tid] = sh.ub[tid];  lb_out[(size_t)g.w * n + base + tid] = sh.lb[tid];
         }
     } else {
-        sweep_tile<512, PPT, false, TC, true, false>(T, sh, px, py, pz, pw, prho, g.y >= 0, nullptr, row, rot, rho, T.code ? lutl : nullptr);
+        sweep_tile<512, PPT, false, TC, true, false>(T, sh, px, py, pz, pw, prho, g.y >= 0, xr, row, rot, rho, T.code ? lutl : nullptr);
         if (tid < TC && base + tid < n) { ub_out[(size_t)by * n + base + tid] = sh.ub[tid]; lb_out[(size_t)by * n + base + tid] = sh.lb[tid]; }
     }
 }
@@ -2744,6 +2757,10 @@ extern "C" int goicp_engine_create(const goicp_engine_desc* d, goicp_engine** ou
     { const char* e = getenv("GOICP_HEAP_CAP"); if (e && atoi(e) >= 16) h->heap_cap = atoi(e); }      // test knob: small queue slabs
     T.NdP = (d->Nd + 1023) & ~1023; T.srot = nullptr; T.srows = nullptr;
     T.exact = (d->parity_mode && d->Nd <= 1024) ? 1 : 0;   // 2*TC*Nd floats of LDS next to the static tile state and the LDS heap
+    // parity_mode 2: reference-order float sums / the reference's intro_select also for clouds of 1025..5120 points (geometric error), on rows in HBM
+    T.exact_big = (d->parity_mode == 2 && d->Nd > 1024 && d->Nd <= 5120 && !use_compat && !use_fpfh) ? 1 : 0;
+    T.xrows = nullptr; T.xslots = 0;
+    if (T.exact_big) { T.xslots = 1024; CR(dev_upload<float>(h, nullptr, (size_t)T.xslots * 2 * TC * T.NdP, &T.xrows)); }
     const size_t ncell = (size_t)d->S * d->S * d->S;
     if (sparse) T.dist = (const float*)d->dt_dist_dev;        // adopted in place (owned by the caller's goicp_dtgpu handle)
     else { float* p_dist; CR(dev_upload(h, d->dt_dist, ncell, &p_dist)); T.dist = p_dist; }
@@ -2899,7 +2916,7 @@ extern "C" int goicp_engine_create(const goicp_engine_desc* d, goicp_engine** ou
             h->fr_mode = 0; h->fr_nsplit = 1; h->fr_ppt = 4; h->fr_block = 512; h->fr_wgs = 2 * std::max(1, ncu); h->fr_heap_cap = 8192;
             h->fr_depth2 = (getenv("GOICP_FR_DEPTH") && atoi(getenv("GOICP_FR_DEPTH")) == 2) ? 1 : 0;   // two-level expansion: measured slower on configs[2] (more sweeps per round than rounds saved); knob kept for deep searches
             const bool fr_off = getenv("GOICP_FR") && atoi(getenv("GOICP_FR")) == 0;          // A/B knob, read once per engine
-            if (!fr_off && !T.exact && !T.use_compat && !T.use_fpfh && d->Nd > 1024) {
+            if ((!fr_off || T.exact_big) && !T.exact && !T.use_compat && !T.use_fpfh && d->Nd > 1024) {
                 if (!h->streamed) { h->fr_mode = 1; h->fr_block = 512; h->fr_ppt = d->Nd <= 2048 ? 4 : (d->Nd <= 4096 ? 8 : 10); h->fr_wgs = 2 * std::max(1, ncu); }
                 else if (T.doTrim) { h->fr_mode = 2; h->fr_block = d->Nd > 16384 ? 1024 : 512; h->fr_wgs = (h->fr_block == 512 ? 2 : 1) * std::max(1, ncu); }
                 else { h->fr_mode = 3; h->fr_block = 1024; h->fr_nsplit = std::min(16, std::max(1, (d->Nd + 6143) / 6144)); h->fr_wgs = std::max(1, ncu); }
@@ -3026,9 +3043,19 @@ static int launch_eval(goicp_engine* h, int slot, int rot_level, const int2* gro
         }
         const int ng = dual ? h->npairs : ngroups, xm = h->xcd_mode;
         const long long wgs = xm == 1 ? 8ll * (((long long)tiles * ng + 7) / 8) : (xm == 2 ? 8ll * ((tiles + 7) / 8) * ng : (long long)tiles * ng);
-#define CALLG(P2) do { if (dual) hipLaunchKernelGGL((k_eval_cubes_geo<P2, true>), dim3((unsigned)wgs), dim3(512), 0, h->stream, h->T, h->d_rot, gtab, (const float*)cubes_dev, n, (float*)ub_dev, (float*)lb_dev, tiles, ng, xm); \
-                       else hipLaunchKernelGGL((k_eval_cubes_geo<P2, false>), dim3((unsigned)wgs), dim3(512), 0, h->stream, h->T, h->d_rot, gtab, (const float*)cubes_dev, n, (float*)ub_dev, (float*)lb_dev, tiles, ng, xm); } while (0)
-        if (h->ppt == 2) CALLG(4); else if (h->ppt == 4) CALLG(8); else CALLG(10);
+#define CALLG(P2) do { if (dual) hipLaunchKernelGGL((k_eval_cubes_geo<P2, true>), dim3((unsigned)wgs), dim3(512), 0, h->stream, h->T, h->d_rot, gtab, (const float*)cubes_dev, n, (float*)ub_dev, (float*)lb_dev, tiles, ng, xm, 0); \
+                       else hipLaunchKernelGGL((k_eval_cubes_geo<P2, false>), dim3((unsigned)wgs), dim3(512), 0, h->stream, h->T, h->d_rot, gtab, (const float*)cubes_dev, n, (float*)ub_dev, (float*)lb_dev, tiles, ng, xm, 0); } while (0)
+        if (h->T.exact_big) {
+            // parity_mode 2: every workgroup owns a slot of row scratch, so the launch goes out in chunks of T.xslots workgroups
+            const long long total = (long long)tiles * ng;
+            for (long long l0 = 0; l0 < total; l0 += h->T.xslots) {
+                const unsigned cw = (unsigned)std::min<long long>(h->T.xslots, total - l0);
+#define CALLX(P2) do { if (dual) hipLaunchKernelGGL((k_eval_cubes_geo<P2, true>), dim3(cw), dim3(512), 0, h->stream, h->T, h->d_rot, gtab, (const float*)cubes_dev, n, (float*)ub_dev, (float*)lb_dev, tiles, ng, 0, (int)l0); \
+                       else hipLaunchKernelGGL((k_eval_cubes_geo<P2, false>), dim3(cw), dim3(512), 0, h->stream, h->T, h->d_rot, gtab, (const float*)cubes_dev, n, (float*)ub_dev, (float*)lb_dev, tiles, ng, 0, (int)l0); } while (0)
+                if (h->ppt == 2) CALLX(4); else if (h->ppt == 4) CALLX(8); else CALLX(10);
+#undef CALLX
+            }
+        } else if (h->ppt == 2) CALLG(4); else if (h->ppt == 4) CALLG(8); else CALLG(10);
 #undef CALLG
         HIPCHK(h, hipGetLastError());
         h->n_cubes += (uint64_t)n * ngroups; h->n_lookups += (uint64_t)n * ngroups * h->T.Nd;
@@ -3255,7 +3282,16 @@ static int ensure_fr(goicp_engine* h, size_t jobs, size_t cap, size_t ecap) {
 
 static void launch_fr_expand(goicp_engine* h, const FrCtx& C, int round, int max_items) {
     const dim3 grid((unsigned)(h->fr_mode == 2 ? std::min(h->fr_wgs, max_items) : max_items));
-#define FRX(B, P, M, NTT) hipLaunchKernelGGL((k_fr_expand<B, P, M, NTT>), grid, dim3(B), 0, h->stream, h->T, C, round)
+    if (h->fr_mode == 1 && h->T.exact_big) {
+        for (int i0 = 0; i0 < max_items; i0 += h->T.xslots) {
+            const dim3 gc((unsigned)std::min(h->T.xslots, max_items - i0));
+#define FRC(B, P) hipLaunchKernelGGL((k_fr_expand<B, P, 0, 4>), gc, dim3(B), 0, h->stream, h->T, C, round, i0)
+            if (h->fr_ppt == 4) FRC(512, 4); else if (h->fr_ppt == 8) FRC(512, 8); else FRC(512, 10);
+#undef FRC
+        }
+        return;
+    }
+#define FRX(B, P, M, NTT) hipLaunchKernelGGL((k_fr_expand<B, P, M, NTT>), grid, dim3(B), 0, h->stream, h->T, C, round, 0)
     if (h->fr_mode == 1) { if (h->fr_ppt == 4) FRX(512, 4, 0, 4); else if (h->fr_ppt == 8) FRX(512, 8, 0, 4); else FRX(512, 10, 0, 4); }
     else if (h->fr_mode == 2) { if (h->fr_block == 512) FRX(512, 1, 1, 8); else FRX(1024, 1, 1, 8); }
     else FRX(1024, 1, 2, 8);

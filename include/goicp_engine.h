@@ -79,7 +79,11 @@ typedef struct goicp_engine_desc {
      *    the point index, and for trimmed runs the reference's own selection (intro_select, same swap sequence) on the
      *    device -- (ub, lb), InnerBnB results and whole registrations are bit-identical to the reference. Larger clouds fall
      *    back to 0.  0: order-free fp64 sums and an exact histogram selection (same inlier multiset; bounds within n*eps of
-     *    the reference, so a search may settle on a different epsilon-optimal node). */
+     *    the reference, so a search may settle on a different epsilon-optimal node).
+     * 2: as 1, and ALSO for geometric runs (no penalty terms) of 1025..5120 points: the addend / residual rows of a tile go to HBM
+     *    and the same sequential sums / intro_select run on them. Bit-identical bounds, searches and registrations (the configs[2]
+     *    pair: same error to the last bit, same queue pops) at roughly 8x the Register() time of mode 1 (0.51 s against 0.066 s;
+     *    reference 10.4 s); a stand-alone sweep of many cubes is far slower (row scratch for 1024 tiles at a time). */
     int32_t parity_mode;
     /* Optional device-resident grid (built by goicp_dtgpu_build below): when dt_dist_dev is non-NULL the engine adopts these
      * buffers in place -- nothing is copied or uploaded, and they must outlive the engine; dt_dist / nearest_occ / cell_color /

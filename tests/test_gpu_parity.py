@@ -695,3 +695,68 @@ def test_streamed_registration_matches_reference_known_answer():
     assert out["stats"]["trans_pops"] == G["pops"]        # (the reference's rotation-queue counter includes its final drain: not comparable)
     assert [a for a, _ in out["trace"]] == [a for a, _ in G["trace"]]
     g.close()
+
+
+@pytest.mark.parametrize("n,S,trim", [(1500, 60, 0.0), (2000, 60, 0.1), (4000, 100, 0.1), (5000, 100, 0.0), (5000, 100, 0.1)])
+def test_parity_mode_2_is_bit_exact_above_1024_points(n, S, trim):
+    """parity_mode 2: clouds of 1025..5120 points (geometric error) with reference-order float sums and, for trimmed runs, the reference's own
+    intro_select on residual rows in HBM -- cube bounds (single launches, fused and unfused multi-group launches) and whole InnerBnB searches
+    (round-based, k_fr_*) equal the oracle bit for bit, as parity_mode 1 does up to 1024 points."""
+    import torch
+    P = synth_pair(n, seed=20260501 + n)
+    v, _ = cfg_vector(distTransSize=S, trimFraction=trim, regularization=0.0, ponderation=0, MSEThresh=0.001)
+    o = oracle_for(P, v); o.initialize()
+    dist, near3, cc, _ = o.dt_dump()
+    e = goicp_amd.Engine(S=S, geom4=(o.geom[0], o.geom[2], o.geom[4], o.geom[6]), dist=dist, data_xyz=P["s"], weights=o.weights(),
+                         maxrotdis=o.maxrotdis(), model_xyz=P["t"], inlier_num=o.inlier_num(), do_trim=trim >= 0.001, norm=2, parity_mode=2)
+    rng = np.random.default_rng(n + S)
+    Rs = [o.axis_angle(rng.uniform(-2, 2, 3).astype(np.float32)) for _ in range(3)]
+    cubes = []
+    for L in (1, 2, 3, 4, 6):
+        w = np.float32(1.0 / 2 ** L)
+        for a in rng.integers(0, 2 ** L, (8, 3)):
+            cubes.append([np.float32(-0.5) + a[0] * w, np.float32(-0.5) + a[1] * w, np.float32(-0.5) + a[2] * w, w])
+    cubes = np.array(cubes, np.float32); nc = len(cubes)
+    want = {}
+    for s_, R in enumerate(Rs):
+        e.set_rotation(s_, R); o.rotate(R)
+        for lv in (-1, 0, 3):
+            want[(s_, lv)] = o.eval_cubes(lv, cubes)
+            ub, lb = e.eval_cubes(s_, lv, cubes)
+            assert np.array_equal(ub, want[(s_, lv)][0]) and np.array_equal(lb, want[(s_, lv)][1]), (n, trim, s_, lv, np.abs(ub - want[(s_, lv)][0]).max())
+    dc = torch.from_numpy(cubes).cuda()
+    for slots, levels in (([0, 0, 1, 1, 2, 2], [-1, 3, -1, 0, 3, -1]), ([0, 1, 2], [3, 0, -1])):      # paired (fused) and unpaired tables
+        ub = torch.zeros((len(slots), nc), device="cuda"); lb = torch.zeros_like(ub)
+        e.eval_cubes_multi_dev(np.array(slots, np.int32), np.array(levels, np.int32), dc.data_ptr(), nc, ub.data_ptr(), lb.data_ptr()); e.synchronize()
+        for g_, (sl, lv) in enumerate(zip(slots, levels)):
+            assert np.array_equal(ub[g_].cpu().numpy(), want[(sl, lv)][0]) and np.array_equal(lb[g_].cpu().numpy(), want[(sl, lv)][1])
+    # whole searches (2x2x2 children tiles through k_fr_expand), same incumbent, same stop rule
+    for s_, R in enumerate(Rs[:2]):
+        o.rotate(R)
+        for lv in (-1, 2):
+            E = np.float32(want[(s_, -1 if lv < 0 else 3)][0].min() * 1.5)
+            o.set_opt_error(E)
+            val, node = o.inner_bnb(lv)
+            r = e.inner_bnb(R=R, level=lv, E=E, sse=np.float32(o.sse_thresh()), init=(-0.5, -0.5, -0.5, 1.0))
+            assert r["status"] == 0 and r["val"] == val, (r["val"], val)
+            if r["found"]:
+                assert np.array_equal(r["node"], node[:4])
+    e.close()
+
+
+def test_c3_headline_pair_is_bit_exact_in_parity_mode_2():
+    """configs[2] pair (5 000 points, 300^3 grid, trimFraction 0.1) through Register() with parity_mode 2: the error equals the compiled
+    reference's known answer (tests/golden/c3_reference.json) to the last bit, with the same trace tags and queue pops."""
+    import json
+    from goicp_amd.synth import synth_pair
+    G = json.load(open(os.path.join(GOLDEN, "c3_reference.json")))
+    P = synth_pair(5000, seed=20260101, theta_range=(2.2, 3.1))
+    g = goicp_amd.GoICP(goicp_amd.cfg_vector(**G["cfg"]), parity_mode=2); g.set_clouds(P["t"], P["s"]); g.build_dt()
+    out = g.register()
+    assert float(out["error"]) == float(np.float32(G["error"])), (out["error"], G["error"])
+    assert np.abs(out["R"] - np.array(G["R"])).max() < 1e-9 and np.abs(out["t"] - np.array(G["t"])).max() < 1e-9
+    assert out["stats"]["trans_pops"] == G["pops"]
+    assert [a for a, _ in out["trace"]] == [a for a, _ in G["trace"]]
+    for (a, x), (b, y) in zip(out["trace"], G["trace"]):
+        assert abs(x - y) <= 6e-6 * abs(y)            # (the known answer holds the reference's 6-digit progress lines)
+    g.close()
