@@ -914,6 +914,149 @@ __device__ __forceinline__ void lattice_fpfh_oct(const DevTables& T, TileShm<BLO
 }
 
 // ---------------------------------------------------------------------------------------------
+// pop_eval_fused: everything a queue pop of a cavity-sized search evaluates (k_inner_bnb, parity mode, untrimmed, penalty terms) in ONE
+// gather phase and ONE sequential-sum phase. sweep_tile + lattice_compat_oct + lattice_fpfh_oct do the same work as three phases of their
+// own (gathers -> barrier -> 16 / 27 sequential chains -> barrier, three times over: 7.2 k + 7.9 k + 13.6 k cycles of a 40 k-cycle pop at 238
+// points). Here a point's 8 distance lookups, 27 compatibility masks and 27 nearest-occupied-cell ids are in flight together (then the 27
+// table entries), the addends / c-FPFH rows go to LDS, and after one barrier the 16 bound chains (wave 0) and the 27 c-FPFH chains (wave 1)
+// run side by side. Same values, same order of every float sum: same bits (reference jly_goicp.cpp:343-415, 431-550, 919-928, 1642-1697).
+// Expects sh.cube / sh.cen / sh.mtd / sh.lat set and sh.cnt[0..26] zeroed behind a barrier.
+// ---------------------------------------------------------------------------------------------
+template <int BLOCK, int PPT>
+__device__ __forceinline__ void pop_eval_fused(const DevTables& T, TileShm<BLOCK>& sh, const float (&px)[PPT], const float (&py)[PPT], const float (&pz)[PPT],
+                                               const float (&pw)[PPT], const float (&prho)[PPT], bool use_rho, float* rbuf /* LDS: 2 x TC x Nd addends */,
+                                               float* fprows /* [27 x Nd], LDS or global */) {
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int Nd = T.Nd, S = T.S;
+    const bool sq = T.norm == 2, lin = T.norm == 1;
+    float* tub = rbuf; float* tlb = rbuf + TC * Nd;
+    int wc[27];
+#pragma unroll
+    for (int l = 0; l < 27; l++) wc[l] = 0;
+#pragma unroll
+    for (int m = 0; m < PPT; m++) {
+        const int i = tid + m * BLOCK;
+        const bool valid = i < Nd;
+        const int ic = min(i, Nd - 1);
+        const float X = px[m], Y = py[m], Z = pz[m];
+        // children: two centre coordinates per axis (sweep_tile, OCT)
+        int rx[2], ry[2], rz[2];
+#pragma unroll
+        for (int q = 0; q < 2; q++) {
+            rx[q] = cell_of(X + sh.cen[q][0], T.xMin, T.scale);
+            ry[q] = cell_of(Y + sh.cen[2 * q][1], T.yMin, T.scale);
+            rz[q] = cell_of(Z + sh.cen[4 * q][2], T.zMin, T.scale);
+        }
+        unsigned idx[TC]; unsigned oob = 0u;
+#pragma unroll
+        for (int j = 0; j < TC; j++) {
+            const int x = rx[j & 1], y = ry[j >> 1 & 1], z = rz[j >> 2 & 1];
+            idx[j] = (unsigned)((clamp_cell(z, S) * S + clamp_cell(y, S)) * S + clamp_cell(x, S));
+            oob |= ((((unsigned)x >= (unsigned)S) | ((unsigned)y >= (unsigned)S) | ((unsigned)z >= (unsigned)S)) ? 1u : 0u) << j;
+        }
+        // corner lattice: three coordinates per axis (lattice_compat_oct / lattice_fpfh_oct)
+        int cx[3], cy[3], cz[3];
+#pragma unroll
+        for (int a = 0; a < 3; a++) {
+            cx[a] = min(max(cell_of(X + sh.lat[a][0], T.xMin, T.scale), 0), S - 1);
+            cy[a] = min(max(cell_of(Y + sh.lat[3 * a][1], T.yMin, T.scale), 0), S - 1);
+            cz[a] = min(max(cell_of(Z + sh.lat[9 * a][2], T.zMin, T.scale), 0), S - 1);
+        }
+        // ---- all first-level gathers of the point
+        float v[TC]; unsigned cd[TC];
+        if (T.code) {
+#pragma unroll
+            for (int j = 0; j < TC; j++) cd[j] = T.code[idx[j]];
+        } else {
+#pragma unroll
+            for (int j = 0; j < TC; j++) v[j] = T.dist[idx[j]];
+        }
+        unsigned mk[27]; int oc[27];
+        if (T.use_compat) {
+#pragma unroll
+            for (int l = 0; l < 27; l++) mk[l] = T.cmask[(size_t)((cz[l / 9] * S + cy[(l / 3) % 3]) * S + cx[l % 3])];
+        }
+        if (T.use_fpfh) {
+#pragma unroll
+            for (int l = 0; l < 27; l++) oc[l] = T.occ[(size_t)((cz[l / 9] * S + cy[(l / 3) % 3]) * S + cx[l % 3])];
+        }
+        const unsigned cls = (unsigned)T.dcls[ic];
+        // ---- second level: decoded distances, table entries
+        if (T.code) {
+#pragma unroll
+            for (int j = 0; j < TC; j++) v[j] = dt_decode(T, idx[j], cd[j], nullptr);
+        }
+        float fe[27];
+        if (T.use_fpfh) {
+            const float* Erow = T.fpE + (size_t)ic * T.nOcc;
+#pragma unroll
+            for (int l = 0; l < 27; l++) fe[l] = Erow[max(oc[l], 0)];
+        }
+        if (__any((int)oob)) {
+#pragma unroll
+            for (int j = 0; j < TC; j++) {
+                // (extension length from the cell coordinates already at hand -- dt_index would redo the three double conversions)
+                if ((oob >> j) & 1u) v[j] = dt_finish(T, v[j], dt_ext_raw(rx[j & 1], ry[j >> 1 & 1], rz[j >> 2 & 1], S));
+            }
+        }
+        // ---- addends of the two bounds (sweep_tile, parity mode, untrimmed)
+        if (valid) {
+#pragma unroll
+            for (int j = 0; j < TC; j++) {
+                float d = pw[m] * v[j];
+                if (use_rho) d -= prho[m];
+                if (d < 0.f) d = 0.f;
+                const float e = d - sh.mtd[j];
+                tub[j * Nd + i] = sq ? d * d : (lin ? d : 0.f);
+                tlb[j * Nd + i] = e > 0.f ? (sq ? e * e : (lin ? e : 0.f)) : 0.f;
+            }
+        }
+        if (T.use_compat) {
+#pragma unroll
+            for (int l = 0; l < 27; l++) wc[l] += __popcll(__ballot(valid && ((mk[l] >> cls) & 1u) == 0u));
+        }
+        if (T.use_fpfh && valid) {
+#pragma unroll
+            for (int l = 0; l < 27; l++) fprows[(size_t)l * Nd + i] = oc[l] < 0 ? 1000000000.f : fe[l];
+        }
+    }
+    if (T.use_compat && lane == 0) {
+#pragma unroll
+        for (int l = 0; l < 27; l++) if (wc[l]) atomicAdd(&sh.cnt[l], wc[l]);
+    }
+    __syncthreads();
+    // ---- the sequential float sums: 16 bound chains on wave 0, 27 c-FPFH chains on wave 1, side by side
+    if (tid < 2 * TC) {
+        const float* tt = rbuf + tid * Nd;          // lanes 0-7: ub rows, lanes 8-15: lb rows
+        float acc = 0.f;
+        int i = 0;
+        for (; i + 16 <= Nd; i += 16) {
+            float t16[16];
+#pragma unroll
+            for (int q = 0; q < 16; q++) t16[q] = tt[i + q];
+#pragma unroll
+            for (int q = 0; q < 16; q++) acc += t16[q];
+        }
+        for (; i < Nd; i++) acc += tt[i];
+        if (tid < TC) sh.ub[tid] = acc; else sh.lb[tid - TC] = acc;
+    } else if (T.use_fpfh && tid >= 64 && tid < 64 + 27) {
+        const float* fr = fprows + (size_t)(tid - 64) * Nd;
+        float acc = 0.f;
+        int i = 0;
+        for (; i + 16 <= Nd; i += 16) {
+            float t16[16];
+#pragma unroll
+            for (int q = 0; q < 16; q++) t16[q] = fr[i + q];
+#pragma unroll
+            for (int q = 0; q < 16; q++) acc += t16[q];
+        }
+        for (; i < Nd; i++) acc += fr[i];
+        sh.fpv[tid - 64] = acc / (float)Nd;
+    }
+    __syncthreads();
+}
+
+// ---------------------------------------------------------------------------------------------
 // binary heap with the element order of std::priority_queue<TRANSNODE> (reference jly_goicp.h:75-87):
 // the hole is sifted to a leaf along the not-lower child, then the displaced value is sifted up.
 // ---------------------------------------------------------------------------------------------
@@ -1544,6 +1687,7 @@ __global__ __launch_bounds__(BLOCK, (BLOCK == 256 ? 2 : (JIT ? 4 : 1))) void k_i
         }
         if (penalties && tid >= 64 && tid < 64 + 27) {
             const int l = tid - 64, ax = l % 3, ay = (l / 3) % 3, az = l / 9;
+            sh.cnt[l] = 0;                                                      // (pop_eval_fused adds into it behind the next barrier)
             const float w = parent.w / 2;
             // coordinate k of the lattice along one axis: p, p+w, (p+w)+w  == child origin + corner offset
             const float x1 = parent.x + w, y1 = parent.y + w, z1 = parent.z + w;
@@ -1553,13 +1697,19 @@ __global__ __launch_bounds__(BLOCK, (BLOCK == 256 ? 2 : (JIT ? 4 : 1))) void k_i
         }
         __syncthreads();
         STAMP(1);
+        bool fused_pop = false;
+        if constexpr (PEN && BLOCK == 256 && !STREAM && !JIT) fused_pop = penalties && T.exact && !T.doTrim && !(T.dbg & 128);
         if constexpr (STREAM) sweep_stream<true>(T, sh, srot, srho, srows, T.NdP);
         else if constexpr (JIT) sweep_tile<BLOCK, PPT, true, TC, true>(T, sh, px, py, pz, pw, prho, use_rho, rbuf, false, srot, srho);
-        else sweep_tile<BLOCK, PPT, true, TC>(T, sh, px, py, pz, pw, prho, use_rho, rbuf);
+        else if constexpr (PEN && BLOCK == 256) {
+            // cavity-sized clouds, parity mode, untrimmed, penalty terms: one gather phase + one sequential-sum phase for all three evaluations
+            if (fused_pop) pop_eval_fused<BLOCK, PPT>(T, sh, px, py, pz, pw, prho, use_rho, rbuf, fpbuf);
+            else sweep_tile<BLOCK, PPT, true, TC>(T, sh, px, py, pz, pw, prho, use_rho, rbuf);
+        } else sweep_tile<BLOCK, PPT, true, TC>(T, sh, px, py, pz, pw, prho, use_rho, rbuf);
         STAMP(2);
-        if (PEN && T.use_compat) lattice_compat_oct<BLOCK, PPT>(T, sh, px, py, pz);
+        if (PEN && T.use_compat && !fused_pop) lattice_compat_oct<BLOCK, PPT>(T, sh, px, py, pz);
         STAMP(3);
-        if (PEN && T.use_fpfh) lattice_fpfh_oct<BLOCK, PPT>(T, sh, px, py, pz, fpbuf);
+        if (PEN && T.use_fpfh && !fused_pop) lattice_fpfh_oct<BLOCK, PPT>(T, sh, px, py, pz, fpbuf);
         STAMP(4);
         if (penalties && tid < 64) {
             // lanes 0-7 of wave 0 fold the corner terms of their child into sh.ub/sh.lb in parallel (only wave 0 reads them next,

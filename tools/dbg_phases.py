@@ -1,6 +1,6 @@
 import os, sys, ctypes as C
 sys.path.insert(0,'/root/repo'); sys.path.insert(0,'/root/repo/tests')
-os.environ["GOICP_DBG"] = "32"
+os.environ["GOICP_DBG"] = os.environ.get("GOICP_DBG", "32")      # (160 = 32 + 128: phases with the fused pop evaluation switched off)
 import numpy as np
 import goicp_amd
 from oracle.refbind import cfg_vector
