@@ -240,67 +240,116 @@ __device__ __forceinline__ void wave_sync_mem() {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
 }
 template <bool MEM = false>
-__device__ __forceinline__ void wave_intro_select(float* d, int* idx, int n, int k, int lane) {
+__device__ __forceinline__ void wave_intro_select(float* d, int* idx, int n, int k, int lane, unsigned long long* st = nullptr /* diagnosis: [0] rows [1] rounds [2] median-of-medians rounds [3] cycles in them [4] cycles in the final insertion sort */) {
     int s = 0, e = n - 1;
     int prev = e - s + 1, tries = 0; bool quick = true;
+    unsigned long long n_rounds = 0, n_mom = 0, c_mom = 0, c_ins = 0, c_a = 0, c_b = 0, c_c = 0, c_d = 0, tq = 0;
     for (;;) {
         if (s >= e) break;
+        n_rounds++;
         if (e - s <= 5) {
+            const unsigned long long t0 = st ? clock64() : 0ull;
             if (lane == 0) { float t; for (int i = s + 1; i <= e; i++) for (int j = i; j > s && d[j - 1] > d[j]; j--) { t = d[j - 1]; d[j - 1] = d[j]; d[j] = t; } }
+            if (st) c_ins += clock64() - t0;
             break;
         }
         if (quick && tries++ == 5) { const int len = e - s + 1; if (len * 2 > prev) quick = false; prev = len; tries = 0; }
-        int pi;
-        if (quick) pi = sel_pivot_ends(d, s, e);                       // three uniform reads
-        else {
+        int pi; float piv, dfront;
+        if (st) tq = clock64();
+        if (quick) {
+            // sel_pivot_ends with its three (uniform) reads kept: the pivot's value is one of them
+            const int m = (s + e) / 2;
+            const float ds = d[s], dm = d[m], de = d[e];
+            if (ds < de) pi = dm < ds ? s : (dm < de ? m : e);
+            else pi = dm < de ? e : (dm < ds ? m : s);
+            piv = pi == s ? ds : (pi == m ? dm : de);
+            dfront = ds;
+        } else {
             int tmp = 0;
+            const unsigned long long t0 = st ? clock64() : 0ull;
             if (lane == 0) tmp = sel_median_of_medians(d, s, e);       // rare fallback: one lane, the reference's in-place group medians
             (MEM ? wave_sync_mem() : wave_sync_lds());
+            if (st) { c_mom += clock64() - t0; n_mom++; }
             pi = __shfl(tmp, 0, 64);
+            piv = d[pi]; dfront = d[s];
         }
-        const float piv = d[pi];
         (MEM ? wave_sync_mem() : wave_sync_lds());
-        if (pi != s && lane == 0) { d[pi] = d[s]; d[s] = piv; }
+        if (pi != s && lane == 0) { d[pi] = dfront; d[s] = piv; }
         (MEM ? wave_sync_mem() : wave_sync_lds());
-        // lane l owns the contiguous chunk [b0, b1) of (s, e]
+        if (st) { const unsigned long long now = clock64(); c_a += now - tq; tq = now; }
+        // The reference's partition loop pairs the i-th element > pivot from the left with the i-th element < pivot from the right and swaps
+        // them while they have not crossed. Ranks by position: the elements of (s, e] are taken 64 at a time (lane = position within the
+        // slice), so a rank is "set bits of the slice's ballot below my lane + the totals of the slices before" -- no scan, no LDS.
         const int L = e - s;                                           // elements besides the pivot
-        const int c = (L + 63) / 64;
-        const int b0 = s + 1 + lane * c, b1 = min(b0 + c, e + 1);
-        int ng = 0, nl = 0;
-        for (int p = b0; p < b1; p++) { const float v = d[p]; ng += v > piv; nl += v < piv; }
-        // exclusive prefix of ng over lanes (left to right) and of nl over lanes (right to left)
-        int pg = ng, pl = nl;
+        int nG = 0, nLt = 0;
+        float v4[4]; unsigned long long g4[4], l4[4];                  // the first four slices stay in registers (every row of <= 257 elements)
 #pragma unroll
-        for (int off = 1; off < 64; off <<= 1) {
-            const int tg = __shfl_up(pg, off, 64); if (lane >= off) pg += tg;
-            const int tl = __shfl_down(pl, off, 64); if (lane + off < 64) pl += tl;
+        for (int q = 0; q < 4; q++) {
+            const int p = s + 1 + lane + 64 * q;
+            const bool in = p <= e;
+            v4[q] = in ? d[p] : piv;
+            g4[q] = __ballot(in && v4[q] > piv); l4[q] = __ballot(in && v4[q] < piv);
+            nG += __popcll(g4[q]); nLt += __popcll(l4[q]);
         }
-        const int nG = __shfl(pg, 63, 64), nLt = __shfl(pl, 0, 64);
-        pg -= ng; pl -= nl;
+        for (int base = 256; base < L; base += 64) {                   // longer rows: count the rest
+            const int p = s + 1 + lane + base;
+            const bool in = p <= e;
+            const float v = in ? d[p] : piv;
+            nG += __popcll(__ballot(in && v > piv)); nLt += __popcll(__ballot(in && v < piv));
+        }
         // idx[i] = position of the i-th '>' from the left; idx[L-1-i] = position of the i-th '<' from the right (nG + nLt <= L)
-        { int rg = pg; for (int p = b0; p < b1; p++) if (d[p] > piv) idx[rg++] = p; }
-        { int rl = pl; for (int p = b1 - 1; p >= b0; p--) if (d[p] < piv) idx[L - 1 - (rl++)] = p; }
+        {
+            int bg = 0, bl = 0;                                        // '>' / '<' met in the slices before
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                const int p = s + 1 + lane + 64 * q;
+                const int below_g = (int)__builtin_amdgcn_mbcnt_hi((unsigned)(g4[q] >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)g4[q], 0u));
+                const int below_l = (int)__builtin_amdgcn_mbcnt_hi((unsigned)(l4[q] >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)l4[q], 0u));
+                if ((g4[q] >> lane) & 1ull) idx[bg + below_g] = p;
+                if ((l4[q] >> lane) & 1ull) idx[L - 1 - (nLt - 1 - (bl + below_l))] = p;
+                bg += __popcll(g4[q]); bl += __popcll(l4[q]);
+            }
+            for (int base = 256; base < L; base += 64) {
+                const int p = s + 1 + lane + base;
+                const bool in = p <= e;
+                const float v = in ? d[p] : piv;
+                const unsigned long long gm = __ballot(in && v > piv), lm = __ballot(in && v < piv);
+                const int below_g = (int)__builtin_amdgcn_mbcnt_hi((unsigned)(gm >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)gm, 0u));
+                const int below_l = (int)__builtin_amdgcn_mbcnt_hi((unsigned)(lm >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)lm, 0u));
+                if ((gm >> lane) & 1ull) idx[bg + below_g] = p;
+                if ((lm >> lane) & 1ull) idx[L - 1 - (nLt - 1 - (bl + below_l))] = p;
+                bg += __popcll(gm); bl += __popcll(lm);
+            }
+        }
         (MEM ? wave_sync_mem() : wave_sync_lds());
+        if (st) { const unsigned long long now = clock64(); c_b += now - tq; tq = now; }
         // pair i is swapped iff its two members have not crossed; pairs are disjoint, so one lane per pair is race-free
         int t = 0;
-        for (int i = lane, m = min(nG, nLt); i < m; i += 64) {
-            const int a = idx[i], b = idx[L - 1 - i];
-            if (a < b) { const float va = d[a]; d[a] = d[b]; d[b] = va; t++; }
+        for (int base = 0, m = min(nG, nLt); base < m; base += 64) {
+            const int i = base + lane;
+            const bool act = i < m;
+            const int a_ = act ? idx[i] : 0, b_ = act ? idx[L - 1 - i] : 0;
+            const bool sw = act && a_ < b_;
+            t += __popcll(__ballot(sw));
+            if (sw) { const float va = d[a_]; d[a_] = d[b_]; d[b_] = va; }
         }
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1) t += __shfl_xor(t, off, 64);
         (MEM ? wave_sync_mem() : wave_sync_lds());
-        // where the reference's scan pointers end up, and where the pivot comes to rest (jly_sorting.hpp:282-303)
-        const int hi0 = t > 0 ? idx[L - 1 - (t - 1)] : e;
+        if (st) { const unsigned long long now = clock64(); c_c += now - tq; tq = now; }
+        // where the reference's scan pointers end up, and where the pivot comes to rest (jly_sorting.hpp:282-303); the three reads go out together
+        const int iA = idx[max(L - t, 0)], iB = idx[min(t, L - 1)];
+        const float dend = d[e];
+        const int hi0 = t > 0 ? iA : e;
         int lo1 = hi0; bool lo_is_greater;
-        if (t < nG && idx[t] < hi0) { lo1 = idx[t]; lo_is_greater = true; }
-        else lo_is_greater = t > 0 ? true : !(d[e] < piv);            // t == 0: d[e] is untouched; '<' means the pivot swaps with it
+        if (t < nG && iB < hi0) { lo1 = iB; lo_is_greater = true; }
+        else lo_is_greater = t > 0 ? true : !(dend < piv);            // t == 0: d[e] is untouched; '<' means the pivot swaps with it
         const int sp = lo_is_greater ? lo1 - 1 : lo1;
         if (lane == 0) { d[s] = d[sp]; d[sp] = piv; }
         (MEM ? wave_sync_mem() : wave_sync_lds());
+        if (st) { const unsigned long long now = clock64(); c_d += now - tq; tq = now; }
         if (sp < k) s = sp + 1; else if (sp > k) e = sp - 1; else break;
     }
     (MEM ? wave_sync_mem() : wave_sync_lds());
+    if (st && lane == 0) { atomicAdd(&st[0], 1ull); atomicAdd(&st[1], n_rounds); atomicAdd(&st[2], n_mom); atomicAdd(&st[3], c_mom); atomicAdd(&st[4], c_ins); atomicAdd(&st[5], c_a); atomicAdd(&st[6], c_b); atomicAdd(&st[7], c_c); }
 }
 
 template <int BLOCK>
@@ -452,7 +501,7 @@ __device__ __forceinline__ void sweep_tile(const DevTables& T, TileShm<BLOCK>& s
         }
         __syncthreads();
         for (int j = tid >> 6; j < NT; j += BLOCK / 64)
-            wave_intro_select<JIT>(rbuf + j * Nd, reinterpret_cast<int*>(rbuf + NT * Nd) + j * Nd, Nd, T.inlierNum - 1, tid & 63);      // (JIT: rows in HBM)
+            wave_intro_select<JIT>(rbuf + j * Nd, reinterpret_cast<int*>(rbuf + NT * Nd) + j * Nd, Nd, T.inlierNum - 1, tid & 63, (T.dbg & 32) && T.dbg_times ? T.dbg_times + 8 : nullptr);      // (JIT: rows in HBM)
         __syncthreads();
         if (tid < 2 * NT) {
             const int j = tid & (NT - 1);

@@ -17,4 +17,8 @@ for name, pn in (("pair1_fpfh","pair1"),("pair1_default","pair1"),("pair1_trim",
     e.L.goicp_engine_debug_times(e.h, out.ctypes.data_as(C.c_void_p))
     pops = int(out[7]); cyc = out[:6].astype(float)
     print(name, "pops", pops, "cycles/pop by phase [pop+ctl, setup, sweep, compat, fpfh, decide+push]:", np.round(cyc / pops).astype(int), "total", int(cyc.sum() / pops), "(s_memtime ticks @100MHz? see note)")
+    if out[8]:
+        print("   selection: rows %d, partition rounds per row %.1f, median-of-medians rounds per row %.2f (%.0f cycles each), final insertion sort %.0f cycles per row" % (
+            out[8], out[9] / out[8], out[10] / out[8], out[11] / max(1, int(out[10])), out[12] / out[8]))
+        print("   cycles per partition round: pivot (incl. median of medians) %.0f | ranks + index lists %.0f | swaps %.0f" % (out[13] / out[9], out[14] / out[9], out[15] / out[9]))
     e.close()
