@@ -211,18 +211,6 @@ __device__ inline int sel_med5(float* d, int s) {
     if (q[0] < q[2]) return q[1] < q[2] ? s + 1 : s + 2;
     return q[0] < q[3] ? s : s + 3;
 }
-__device__ inline int sel_median_of_medians(float* d, int s, int e) {
-    for (;;) {                                  // the reference recurses on the block of medians it has just moved to the front
-        const int len = e - s + 1, groups = len / 5 + (len % 5 != 0);
-        int g = s, i = 0, mi; float t;
-        for (; i + 1 < groups; i++, g += 5) { mi = sel_med5(d, g); t = d[s + i]; d[s + i] = d[mi]; d[mi] = t; }
-        const int rest = e - g + 1;
-        mi = (rest == 3 || rest == 4) ? sel_med3(d, g) : (rest == 5 ? sel_med5(d, g) : g);
-        t = d[s + i]; d[s + i] = d[mi]; d[mi] = t;
-        if (groups > 5) { e = s + groups - 1; continue; }
-        return (groups == 3 || groups == 4) ? sel_med3(d, s) : (groups == 5 ? sel_med5(d, s) : s);
-    }
-}
 // Wave-parallel form of the same selection: one wave per residual row. The reference's partition loop pairs the i-th element
 // > pivot from the left with the i-th element < pivot from the right and swaps them while they have not crossed; that final
 // arrangement (and the pivot's resting place) is a pure function of the row, so it is computed with ballots / prefix counts
@@ -238,6 +226,46 @@ __device__ __forceinline__ void wave_sync_mem() {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+}
+// sel_median_of_medians for a whole wave. The group medians of a pass are independent of each other (a group is only modified by its own
+// sel_med5 and, later, by front swaps of groups 5 times further on), so every lane takes groups of its own: sel_med5 in registers with the
+// reference's in-place moves written back. The front swaps "d[s+i] <-> d[median of group i]" keep the sequential result when they are applied
+// level by level: swap i can only meet swap floor(i/5) (whose group holds the slot s+i), so swaps [0,1), [1,5), [5,25), [25,125), ... are
+// independent inside a level. The last (short) group and the final choice stay on lane 0 (sel_med3 reads absolute indices, jly_sorting.hpp:74-80).
+// idx: scratch of at least (e - s + 1) / 5 + 1 ints. Returns the pivot's index (uniform).
+template <bool MEM>
+__device__ __forceinline__ int wave_median_of_medians(float* d, int* idx, int s, int e, int lane) {
+    for (;;) {
+        const int len = e - s + 1, groups = len / 5 + (len % 5 != 0);
+        const int nfull = groups - 1;                                  // groups that are certainly complete (the loop of the reference)
+        for (int it = lane; it < nfull; it += 64) {
+            float* q = d + s + 5 * it;
+            float q0 = q[0], q1 = q[1], q2 = q[2], q3 = q[3], q4 = q[4], t;
+            if (q0 > q1) { t = q0; q0 = q1; q1 = t; }
+            if (q2 > q3) { t = q2; q2 = q3; q3 = t; }
+            int m;
+            if (q0 < q2) { t = q4; q4 = q0; if (t < q1) q0 = t; else { q0 = q1; q1 = t; } }
+            else { t = q4; q4 = q2; if (t < q3) q2 = t; else { q2 = q3; q3 = t; } }
+            if (q0 < q2) m = q1 < q2 ? 1 : 2; else m = q0 < q3 ? 0 : 3;
+            q[0] = q0; q[1] = q1; q[2] = q2; q[3] = q3; q[4] = q4;
+            idx[it] = s + 5 * it + m;
+        }
+        (MEM ? wave_sync_mem() : wave_sync_lds());
+        for (int lo = 0, hi = 1; lo < nfull; lo = hi, hi *= 5) {
+            for (int i = lo + lane; i < min(hi, nfull); i += 64) { const int mi = idx[i]; const float t = d[s + i]; d[s + i] = d[mi]; d[mi] = t; }
+            (MEM ? wave_sync_mem() : wave_sync_lds());
+        }
+        int ret = 0;
+        if (lane == 0) {
+            const int g = s + 5 * nfull, rest = e - g + 1;
+            const int mi = (rest == 3 || rest == 4) ? sel_med3(d, g) : (rest == 5 ? sel_med5(d, g) : g);
+            const float t = d[s + nfull]; d[s + nfull] = d[mi]; d[mi] = t;
+            if (groups <= 5) ret = (groups == 3 || groups == 4) ? sel_med3(d, s) : (groups == 5 ? sel_med5(d, s) : s);
+        }
+        (MEM ? wave_sync_mem() : wave_sync_lds());
+        if (groups > 5) { e = s + groups - 1; continue; }
+        return __shfl(ret, 0, 64);
+    }
 }
 template <bool MEM = false>
 __device__ __forceinline__ void wave_intro_select(float* d, int* idx, int n, int k, int lane, unsigned long long* st = nullptr /* diagnosis: [0] rows [1] rounds [2] median-of-medians rounds [3] cycles in them [4] cycles in the final insertion sort */) {
@@ -267,10 +295,9 @@ __device__ __forceinline__ void wave_intro_select(float* d, int* idx, int n, int
         } else {
             int tmp = 0;
             const unsigned long long t0 = st ? clock64() : 0ull;
-            if (lane == 0) tmp = sel_median_of_medians(d, s, e);       // rare fallback: one lane, the reference's in-place group medians
-            (MEM ? wave_sync_mem() : wave_sync_lds());
+            tmp = wave_median_of_medians<MEM>(d, idx, s, e, lane);      // fallback of a selection that does not make progress: the reference's in-place group medians
             if (st) { c_mom += clock64() - t0; n_mom++; }
-            pi = __shfl(tmp, 0, 64);
+            pi = tmp;
             piv = d[pi]; dfront = d[s];
         }
         (MEM ? wave_sync_mem() : wave_sync_lds());
@@ -291,11 +318,12 @@ __device__ __forceinline__ void wave_intro_select(float* d, int* idx, int n, int
             g4[q] = __ballot(in && v4[q] > piv); l4[q] = __ballot(in && v4[q] < piv);
             nG += __popcll(g4[q]); nLt += __popcll(l4[q]);
         }
-        for (int base = 256; base < L; base += 64) {                   // longer rows: count the rest
-            const int p = s + 1 + lane + base;
-            const bool in = p <= e;
-            const float v = in ? d[p] : piv;
-            nG += __popcll(__ballot(in && v > piv)); nLt += __popcll(__ballot(in && v < piv));
+        for (int base = 256; base < L; base += 256) {                  // longer rows: count the rest, four slices (reads) at a time
+            float v[4];
+#pragma unroll
+            for (int q = 0; q < 4; q++) { const int p = s + 1 + lane + base + 64 * q; v[q] = p <= e ? d[p] : piv; }
+#pragma unroll
+            for (int q = 0; q < 4; q++) { nG += __popcll(__ballot(v[q] > piv)); nLt += __popcll(__ballot(v[q] < piv)); }
         }
         // idx[i] = position of the i-th '>' from the left; idx[L-1-i] = position of the i-th '<' from the right (nG + nLt <= L)
         {
@@ -309,16 +337,20 @@ __device__ __forceinline__ void wave_intro_select(float* d, int* idx, int n, int
                 if ((l4[q] >> lane) & 1ull) idx[L - 1 - (nLt - 1 - (bl + below_l))] = p;
                 bg += __popcll(g4[q]); bl += __popcll(l4[q]);
             }
-            for (int base = 256; base < L; base += 64) {
-                const int p = s + 1 + lane + base;
-                const bool in = p <= e;
-                const float v = in ? d[p] : piv;
-                const unsigned long long gm = __ballot(in && v > piv), lm = __ballot(in && v < piv);
-                const int below_g = (int)__builtin_amdgcn_mbcnt_hi((unsigned)(gm >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)gm, 0u));
-                const int below_l = (int)__builtin_amdgcn_mbcnt_hi((unsigned)(lm >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)lm, 0u));
-                if ((gm >> lane) & 1ull) idx[bg + below_g] = p;
-                if ((lm >> lane) & 1ull) idx[L - 1 - (nLt - 1 - (bl + below_l))] = p;
-                bg += __popcll(gm); bl += __popcll(lm);
+            for (int base = 256; base < L; base += 256) {
+                float v[4];
+#pragma unroll
+                for (int q = 0; q < 4; q++) { const int p = s + 1 + lane + base + 64 * q; v[q] = p <= e ? d[p] : piv; }      // (out of range: equal to the pivot, in neither set)
+#pragma unroll
+                for (int q = 0; q < 4; q++) {
+                    const int p = s + 1 + lane + base + 64 * q;
+                    const unsigned long long gm = __ballot(v[q] > piv), lm = __ballot(v[q] < piv);
+                    const int below_g = (int)__builtin_amdgcn_mbcnt_hi((unsigned)(gm >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)gm, 0u));
+                    const int below_l = (int)__builtin_amdgcn_mbcnt_hi((unsigned)(lm >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)lm, 0u));
+                    if ((gm >> lane) & 1ull) idx[bg + below_g] = p;
+                    if ((lm >> lane) & 1ull) idx[L - 1 - (nLt - 1 - (bl + below_l))] = p;
+                    bg += __popcll(gm); bl += __popcll(lm);
+                }
             }
         }
         (MEM ? wave_sync_mem() : wave_sync_lds());

@@ -82,8 +82,8 @@ typedef struct goicp_engine_desc {
      *    the reference, so a search may settle on a different epsilon-optimal node).
      * 2: as 1, and ALSO for geometric runs (no penalty terms) of 1025..5120 points: the addend / residual rows of a tile go to HBM
      *    and the same sequential sums / intro_select run on them. Bit-identical bounds, searches and registrations (the configs[2]
-     *    pair: same error to the last bit, same queue pops) at roughly 8x the Register() time of mode 1 (0.51 s against 0.066 s;
-     *    reference 10.4 s); a stand-alone sweep of many cubes is far slower (row scratch for 1024 tiles at a time). */
+     *    pair: same error to the last bit, same queue pops) at about twice the Register() time of mode 1 (0.124 s against 0.066 s;
+     *    reference 10.4 s); a stand-alone sweep of many cubes is far slower (row scratch for 1024 tiles at a time: 94 ms against 2 ms). */
     int32_t parity_mode;
     /* Optional device-resident grid (built by goicp_dtgpu_build below): when dt_dist_dev is non-NULL the engine adopts these
      * buffers in place -- nothing is copied or uploaded, and they must outlive the engine; dt_dist / nearest_occ / cell_color /
