@@ -59,7 +59,7 @@ def algorithmic_bytes_per_cube_eval(nd):
 def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=300, help="timed launches (3.4 ms each at the default shape: ~1 s)")
+    ap.add_argument("--steps", type=int, default=600, help="timed launches (2.0 ms each at the default shape: ~1.2 s)")
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--points", type=int, default=N_POINTS)
     ap.add_argument("--dt", type=int, default=DT_SIZE)

@@ -62,6 +62,7 @@ struct DevTables {
     float reg, regFPFH;
     int use_compat, use_fpfh, exact;
     int exact_big;           // parity_mode 2, 1025..5120 points, geometric error: reference-order sums / intro_select on residual rows in HBM (xrows)
+    int exact_stream;        // parity_mode 2 on a streamed cloud: the same on [2 * TC][NdP] rows per resident workgroup (srows)
     float* xrows; int xslots; // [xslots][2 * TC * NdP] floats: addend / residual rows + selection scratch of one workgroup each
     float4* srot;            // streaming path (Nd > 8192): per-workgroup rotated cloud [NdP]
     float* srows;            // streaming path, trimmed runs: per-workgroup residual rows [TC][NdP]
@@ -1301,6 +1302,86 @@ __device__ __forceinline__ void sweep_stream(const DevTables& T, TileShm<BLOCK>&
     const bool row_mode = !OCT && sh.ctl[2];
     const bool sq = T.norm == 2, lin = T.norm == 1;
     const bool trim = !PARTIAL && T.doTrim != 0;
+    if (!PARTIAL && T.exact_stream) {
+        // parity_mode 2 on a streamed cloud: the addend rows (untrimmed: 8 ub + 8 lb rows) or the residual rows (trimmed: 8 rows + 8 rows of
+        // selection scratch) of the tile go to this workgroup's [2 * TC][NdP] rows in HBM; then the reference-order arithmetic of sweep_tile's
+        // parity branches runs on them: one wave per cube for intro_select, 16 lanes for the 16 sequential float sums (jly_goicp.cpp:384-415).
+        constexpr int PB = BLOCK / 8, U = 8;
+        const int j = tid & 7, q = tid >> 3;
+        const float cx = sh.cen[j][0], cy = sh.cen[j][1], cz = sh.cen[j][2], mtd = sh.mtd[j];
+        for (int b = 0; b < Nd; b += PB * U) {
+            unsigned idx[U]; float w[U], rh[U], ext[U]; bool valid[U];
+#pragma unroll
+            for (int k = 0; k < U; k++) {
+                const int i = b + q + k * PB;
+                valid[k] = i < Nd;
+                const float4 p = rot[min(i, Nd - 1)];
+                rh[k] = rho_row ? rho_row[min(i, Nd - 1)] : 0.f;
+                const int x = cell_of(p.x + cx, T.xMin, T.scale), y = cell_of(p.y + cy, T.yMin, T.scale), z = cell_of(p.z + cz, T.zMin, T.scale);
+                idx[k] = (unsigned)((clamp_cell(z, S) * S + clamp_cell(y, S)) * S + clamp_cell(x, S));
+                ext[k] = dt_ext_raw(x, y, z, S);
+                w[k] = p.w;
+            }
+            float v[U];
+            if (T.code) {
+                unsigned c[U];
+#pragma unroll
+                for (int k = 0; k < U; k++) c[k] = T.code[idx[k]];
+#pragma unroll
+                for (int k = 0; k < U; k++) v[k] = dt_decode(T, idx[k], c[k], nullptr);
+            } else {
+#pragma unroll
+                for (int k = 0; k < U; k++) v[k] = T.dist[idx[k]];
+            }
+#pragma unroll
+            for (int k = 0; k < U; k++) {
+                float d = w[k] * dt_finish(T, v[k], ext[k]);
+                if (rho_row) d -= rh[k];
+                if (d < 0.f) d = 0.f;
+                const int i = b + q + k * PB;
+                if (valid[k]) {
+                    if (trim) rows[(size_t)j * NdP + i] = d;
+                    else {
+                        const float e = d - mtd;
+                        rows[(size_t)j * NdP + i] = sq ? d * d : (lin ? d : 0.f);
+                        rows[(size_t)(TC + j) * NdP + i] = e > 0.f ? (sq ? e * e : (lin ? e : 0.f)) : 0.f;
+                    }
+                }
+            }
+        }
+        __syncthreads();
+        if (trim) {
+            if (wv < TC) wave_intro_select<true>(rows + (size_t)wv * NdP, reinterpret_cast<int*>(rows + (size_t)(TC + wv) * NdP), Nd, T.inlierNum - 1, ln);
+            __syncthreads();
+        }
+        if (tid < 2 * TC) {
+            const int cj = tid & (TC - 1);
+            const bool is_lb = tid >= TC;
+            const float* rr = trim ? rows + (size_t)cj * NdP : rows + (size_t)tid * NdP;
+            const float sub = (trim && is_lb) ? sh.mtd[cj] : 0.f;
+            const int cnt = trim ? T.inlierNum : Nd;
+            float acc = 0.f;
+            auto add = [&](float d) {
+                if (!trim) { acc += d; return; }                    // (addends formed above)
+                const float e = d - sub;                            // (d - 0 == d exactly for the ub chain)
+                float term = sq ? e * e : (lin ? e : 0.f);
+                if (is_lb && !(e > 0.f)) term = 0.f;
+                acc += term;
+            };
+            int i = 0;
+            for (; i + 32 <= cnt; i += 32) {                        // 32 reads in flight, then the 32 dependent adds
+                float t32[32];
+#pragma unroll
+                for (int k = 0; k < 32; k++) t32[k] = rr[i + k];
+#pragma unroll
+                for (int k = 0; k < 32; k++) add(t32[k]);
+            }
+            for (; i < cnt; i++) add(rr[i]);
+            if (is_lb) sh.lb[cj] = acc; else sh.ub[cj] = acc;
+        }
+        __syncthreads();
+        return;
+    }
     if (!trim) {
         // Untrimmed runs keep nothing per point, so the sweep runs with lane = (point, cube): lane l adds up cube l & 7 over the points
         // (l >> 3) + BLOCK/8 * k. The 8 lanes of a point read cells of nearby grid rows / one row, i.e. 8-32 cache lines per wave instruction
@@ -1692,7 +1773,7 @@ __global__ __launch_bounds__(BLOCK, (BLOCK == 256 ? 2 : (JIT ? 4 : 1))) void k_i
     float4* srot = nullptr; float* srows = nullptr; const float* srho = nullptr;
     if constexpr (STREAM || JIT) {
         srot = T.srot + (size_t)blockIdx.x * T.NdP;
-        srows = T.srows ? T.srows + (size_t)blockIdx.x * TC * T.NdP : nullptr;
+        srows = T.srows ? T.srows + (size_t)blockIdx.x * (T.exact_stream ? 2 : 1) * TC * T.NdP : nullptr;
         srho = use_rho ? T.maxRotDis + (size_t)job.rot_level * Nd : nullptr;
         for (int i = tid; i < Nd; i += BLOCK) {
             const float x = T.dxyz[3 * i], y = T.dxyz[3 * i + 1], z = T.dxyz[3 * i + 2];
@@ -2109,7 +2190,7 @@ __global__ __launch_bounds__(BLOCK, (MODE == 0 ? 4 : (BLOCK == 512 ? 4 : 1))) vo
     const unsigned n = min(C.wl_count[round], (unsigned)C.wl_cap);
     if constexpr (MODE == 1) {
         // a residual-row scratch per resident workgroup: persistent workgroups walk the list
-        float* rows = T.srows ? T.srows + (size_t)blockIdx.x * TC * T.NdP : nullptr;
+        float* rows = T.srows ? T.srows + (size_t)blockIdx.x * (T.exact_stream ? 2 : 1) * TC * T.NdP : nullptr;
         for (unsigned it = blockIdx.x; it < n; it += gridDim.x) {
             fr_expand_item<BLOCK, PPT, MODE, NT>(T, C, sh, C.wl[it], rows, lutl);
             __syncthreads();
@@ -2134,7 +2215,7 @@ __global__ __launch_bounds__(BLOCK, (BLOCK == 512 ? 4 : 1)) void k_eval_cubes_st
     __shared__ TileShm<BLOCK> sh;
     const int tid = threadIdx.x;
     const int Nd = T.Nd;
-    float* rows = T.srows ? T.srows + (size_t)blockIdx.x * TC * T.NdP : nullptr;
+    float* rows = T.srows ? T.srows + (size_t)blockIdx.x * (T.exact_stream ? 2 : 1) * TC * T.NdP : nullptr;
     const int tiles = (n + TC - 1) / TC;
     const long long total = (long long)tiles * ngroups;            // (ngroups = number of pairs when `pairs` is given)
     for (long long w = blockIdx.x; w < total; w += gridDim.x) {
@@ -2783,14 +2864,17 @@ static hipError_t cache_stream_aux(int device, int kind, hipStream_t* st) {
     if (kind == 0) {
         int lo = 0, hi = 0;                                    // (numerically lower = higher priority)
         if (hipDeviceGetStreamPriorityRange(&lo, &hi) != hipSuccess) { lo = 0; hi = 0; }
-        return hipStreamCreateWithPriority(st, hipStreamNonBlocking, hi);
+        if (hipStreamCreateWithPriority(st, hipStreamNonBlocking, hi) == hipSuccess) return hipSuccess;
+        (void)hipGetLastError();
+        return hipStreamCreateWithFlags(st, hipStreamNonBlocking);
     }
     int reserve = 16, ncu = 0;
     { const char* r = getenv("GOICP_CU_RESERVE"); if (r) reserve = atoi(r); }
     if (reserve > 0 && hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && 2 * reserve <= ncu) {
         std::vector<uint32_t> mask((size_t)(ncu + 31) / 32, 0u);
         for (int c = 0; c < ncu - reserve; c++) mask[(size_t)c / 32] |= 1u << (c % 32);
-        return hipExtStreamCreateWithCUMask(st, (uint32_t)mask.size(), mask.data());
+        if (hipExtStreamCreateWithCUMask(st, (uint32_t)mask.size(), mask.data()) == hipSuccess) return hipSuccess;
+        (void)hipGetLastError();                               // (a runtime without CU masks: an ordinary stream does the job, only slower in a batch)
     }
     return hipStreamCreateWithFlags(st, hipStreamNonBlocking);
 }
@@ -2990,6 +3074,7 @@ extern "C" int goicp_engine_create(const goicp_engine_desc* d, goicp_engine** ou
     T.exact = (d->parity_mode && d->Nd <= 1024) ? 1 : 0;   // 2*TC*Nd floats of LDS next to the static tile state and the LDS heap
     // parity_mode 2: reference-order float sums / the reference's intro_select also for clouds of 1025..5120 points (geometric error), on rows in HBM
     T.exact_big = (d->parity_mode == 2 && d->Nd > 1024 && d->Nd <= 5120 && !use_compat && !use_fpfh) ? 1 : 0;
+    T.exact_stream = (d->parity_mode == 2 && d->Nd > 5120 && !use_compat && !use_fpfh) ? 1 : 0;      // (geometric runs above 5120 points are streamed, pick_geometry)
     T.xrows = nullptr; T.xslots = 0;
     if (T.exact_big) { T.xslots = 1024; CR(dev_upload<float>(h, nullptr, (size_t)T.xslots * 2 * TC * T.NdP, &T.xrows)); }
     const size_t ncell = (size_t)d->S * d->S * d->S;
@@ -3147,9 +3232,10 @@ extern "C" int goicp_engine_create(const goicp_engine_desc* d, goicp_engine** ou
             h->fr_mode = 0; h->fr_nsplit = 1; h->fr_ppt = 4; h->fr_block = 512; h->fr_wgs = 2 * std::max(1, ncu); h->fr_heap_cap = 8192;
             h->fr_depth2 = (getenv("GOICP_FR_DEPTH") && atoi(getenv("GOICP_FR_DEPTH")) == 2) ? 1 : 0;   // two-level expansion: measured slower on configs[2] (more sweeps per round than rounds saved); knob kept for deep searches
             const bool fr_off = getenv("GOICP_FR") && atoi(getenv("GOICP_FR")) == 0;          // A/B knob, read once per engine
-            if ((!fr_off || T.exact_big) && !T.exact && !T.use_compat && !T.use_fpfh && d->Nd > 1024) {
+            if ((!fr_off || T.exact_big || T.exact_stream) && !T.exact && !T.use_compat && !T.use_fpfh && d->Nd > 1024) {
                 if (!h->streamed) { h->fr_mode = 1; h->fr_block = 512; h->fr_ppt = d->Nd <= 2048 ? 4 : (d->Nd <= 4096 ? 8 : 10); h->fr_wgs = 2 * std::max(1, ncu); }
-                else if (T.doTrim) { h->fr_mode = 2; h->fr_block = d->Nd > 16384 ? 1024 : 512; h->fr_wgs = (h->fr_block == 512 ? 2 : 1) * std::max(1, ncu); }
+                else if (T.doTrim || T.exact_stream) { h->fr_mode = 2;      // (parity_mode 2: whole tiles, the sums run over all points in index order)
+                    h->fr_block = d->Nd > 16384 ? 1024 : 512; h->fr_wgs = (h->fr_block == 512 ? 2 : 1) * std::max(1, ncu); }
                 else { h->fr_mode = 3; h->fr_block = 1024; h->fr_nsplit = std::min(16, std::max(1, (d->Nd + 6143) / 6144)); h->fr_wgs = std::max(1, ncu); }
                 { const char* e = getenv("GOICP_HEAP_CAP"); if (e && atoi(e) >= 16) h->fr_heap_cap = atoi(e); }
                 h->resident_jobs = std::max(h->resident_jobs, 32);
@@ -3224,11 +3310,11 @@ static int ensure_stream_scratch(goicp_engine* h, size_t wgs, bool need_rot, boo
         HIPCHK(h, cache_malloc((void**)&h->T.srot, wgs * (size_t)h->T.NdP * sizeof(float4), h->device));
         h->stream_rot_wgs = wgs;
     }
-    if (need_rows && h->T.doTrim && wgs > h->stream_wgs) {
+    if (need_rows && (h->T.doTrim || h->T.exact_stream) && wgs > h->stream_wgs) {
         HIPCHK(h, hipStreamSynchronize(h->stream));
         if (h->T.srows) { cache_free(h->T.srows); h->T.srows = nullptr; }
         h->stream_wgs = 0;
-        HIPCHK(h, cache_malloc((void**)&h->T.srows, wgs * (size_t)TC * h->T.NdP * sizeof(float), h->device));
+        HIPCHK(h, cache_malloc((void**)&h->T.srows, wgs * (size_t)(h->T.exact_stream ? 2 : 1) * TC * h->T.NdP * sizeof(float), h->device));
         h->stream_wgs = wgs;
     }
     return GOICP_OK;
@@ -3237,7 +3323,7 @@ static int ensure_stream_scratch(goicp_engine* h, size_t wgs, bool need_rot, boo
 static int launch_eval(goicp_engine* h, int slot, int rot_level, const int2* groups_dev, int ngroups, const void* cubes_dev, int n, void* ub_dev, void* lb_dev) {
     if (h->streamed) {
         // untrimmed runs: group pairs (no radius / radius, same slot) of a multi-group call are evaluated from one pass of gathers when all pair up
-        const bool dual = !h->T.doTrim && groups_dev == h->d_groups && h->npairs > 0 && h->npairs * 2 == ngroups;
+        const bool dual = !h->T.doTrim && !h->T.exact_stream && groups_dev == h->d_groups && h->npairs > 0 && h->npairs * 2 == ngroups;
         const int ng = dual ? h->npairs : ngroups;
         const int4* ptab = dual ? h->d_pairs : nullptr;
         h->last_fused = dual ? 1 : 0;

@@ -80,7 +80,7 @@ typedef struct goicp_engine_desc {
      *    device -- (ub, lb), InnerBnB results and whole registrations are bit-identical to the reference. Larger clouds fall
      *    back to 0.  0: order-free fp64 sums and an exact histogram selection (same inlier multiset; bounds within n*eps of
      *    the reference, so a search may settle on a different epsilon-optimal node).
-     * 2: as 1, and ALSO for geometric runs (no penalty terms) of 1025..5120 points: the addend / residual rows of a tile go to HBM
+     * 2: as 1, and ALSO for geometric runs (no penalty terms) above 1024 points (register-resident or streamed): the addend / residual rows of a tile go to HBM
      *    and the same sequential sums / intro_select run on them. Bit-identical bounds, searches and registrations (the configs[2]
      *    pair: same error to the last bit, same queue pops) at about twice the Register() time of mode 1 (0.124 s against 0.066 s;
      *    reference 10.4 s); a stand-alone sweep of many cubes is far slower (row scratch for 1024 tiles at a time: 94 ms against 2 ms). */

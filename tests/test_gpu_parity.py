@@ -489,15 +489,16 @@ def test_full_size_properties(n, S, trim):
     g.close()
 
 
-@pytest.mark.parametrize("n,S,trim,mse", [(50000, 500, 0.0, 1e-5), (5000, 300, 0.1, 1e-3)])
-def test_bounded_search_prefix_against_the_oracle(n, S, trim, mse):
+@pytest.mark.parametrize("n,S,trim,mse,pm", [(50000, 500, 0.0, 1e-5, 1), (5000, 300, 0.1, 1e-3, 1), (50000, 500, 0.0, 1e-5, 2), (5000, 300, 0.1, 1e-3, 2)])
+def test_bounded_search_prefix_against_the_oracle(n, S, trim, mse, pm):
     """BASELINE configs[4] (50 000 points, 500^3 grid, MSEThresh 1e-5: a deep search nobody runs to the end on one CPU core) and
     configs[2]: the first 250 queue pops = 2 000 cube evaluations of searches from the root, on the device
     (job.max_pops) and in the oracle (pop budget) on the same grid: same best node, upper bound within max(1e-5, n*2^-24)
-    relative, same number of pops -- for a ub-call and an lb-call, under three rotations."""
+    relative, same number of pops -- for a ub-call and an lb-call, under three rotations. With parity_mode 2 (reference-order sums on rows in
+    HBM, also for the streamed 50 000-point cloud) the upper bound is the oracle's to the last bit."""
     P = synth_pair(n)
     v, _ = cfg_vector(distTransSize=S, trimFraction=trim, regularization=0.0, ponderation=0, MSEThresh=mse)
-    g = goicp_amd.GoICP(v); g.set_clouds(P["t"], P["s"]); g.build_dt(); g.initialize()
+    g = goicp_amd.GoICP(v, parity_mode=pm); g.set_clouds(P["t"], P["s"]); g.build_dt(); g.initialize()
     e = g.engine()
     dist, _, _ = g.dt_dump()
     from oracle.refbind import Oracle
@@ -517,7 +518,10 @@ def test_bounded_search_prefix_against_the_oracle(n, S, trim, mse):
         val, node = o.inner_bnb(j["level"])
         pops = o.counters(reset=True)[0]
         assert r["status"] in (0, 5) and r["pops"] == pops, (r["pops"], pops)
-        assert abs(float(r["val"]) - float(val)) <= rtol * abs(float(val)), (r["val"], val)
+        if pm == 2:
+            assert float(r["val"]) == float(val), (r["val"], val)
+        else:
+            assert abs(float(r["val"]) - float(val)) <= rtol * abs(float(val)), (r["val"], val)
         assert r["found"] and np.array_equal(r["node"], np.asarray(node[:4], np.float32))
     g.close()
 
@@ -697,11 +701,12 @@ def test_streamed_registration_matches_reference_known_answer():
     g.close()
 
 
-@pytest.mark.parametrize("n,S,trim", [(1500, 60, 0.0), (2000, 60, 0.1), (4000, 100, 0.1), (5000, 100, 0.0), (5000, 100, 0.1)])
+@pytest.mark.parametrize("n,S,trim", [(1500, 60, 0.0), (2000, 60, 0.1), (4000, 100, 0.1), (5000, 100, 0.0), (5000, 100, 0.1), (9000, 100, 0.0), (9000, 100, 0.1), (20000, 100, 0.1)])
 def test_parity_mode_2_is_bit_exact_above_1024_points(n, S, trim):
-    """parity_mode 2: clouds of 1025..5120 points (geometric error) with reference-order float sums and, for trimmed runs, the reference's own
-    intro_select on residual rows in HBM -- cube bounds (single launches, fused and unfused multi-group launches) and whole InnerBnB searches
-    (round-based, k_fr_*) equal the oracle bit for bit, as parity_mode 1 does up to 1024 points."""
+    """parity_mode 2: clouds above 1024 points (geometric error; register-resident up to 5120 points, streamed from HBM beyond) with
+    reference-order float sums and, for trimmed runs, the reference's own intro_select on residual rows in HBM -- cube bounds (single launches,
+    fused and unfused multi-group launches) and whole InnerBnB searches (round-based, k_fr_*) equal the oracle bit for bit, as parity_mode 1
+    does up to 1024 points."""
     import torch
     P = synth_pair(n, seed=20260501 + n)
     v, _ = cfg_vector(distTransSize=S, trimFraction=trim, regularization=0.0, ponderation=0, MSEThresh=0.001)
