@@ -2721,6 +2721,7 @@ __global__ __launch_bounds__(1024) void k_icp_loop(DevTables T, const float* __r
 struct goicp_engine {
     int device;
     hipStream_t stream;
+    int upload_defer;                         // goicp_engine_create: uploads are waited for once, at its end (their sources live that long)
     hipStream_t stream_bulk;                  // search launches of cavity-sized engines (see cache_stream_aux); null: they use `stream`
     hipStream_t stream_hi;                    // high-priority stream for the small latency-critical kernels (ICP 1-NN, point evaluation): beside other
                                               // engines' bulk search launches they would otherwise queue behind thousands of search workgroups
@@ -2914,10 +2915,10 @@ static int dev_upload(goicp_engine* h, const Tp* src, size_t n, Tp** out) {
     HIPCHK(h, cache_malloc((void**)&p, std::max<size_t>(n, 1) * sizeof(Tp), h->device));
     h->allocs.push_back(p);
     if (src && n) {
-        // on the engine's own (non-blocking) stream, then waited for: the source may be a temporary of the caller, and a copy on the
-        // default stream would wait for the kernels of every other engine in the process
+        // on the engine's own (non-blocking) stream: a copy on the default stream would wait for the kernels of every other engine in the
+        // process. goicp_engine_create keeps every source alive and waits ONCE at its end (upload_defer); elsewhere the copy is waited for here.
         HIPCHK(h, hipMemcpyAsync(p, src, n * sizeof(Tp), hipMemcpyHostToDevice, h->stream));
-        HIPCHK(h, hipStreamSynchronize(h->stream));
+        if (!h->upload_defer) HIPCHK(h, hipStreamSynchronize(h->stream));
     }
     *out = p;
     return GOICP_OK;
@@ -3035,7 +3036,7 @@ extern "C" int goicp_engine_create(const goicp_engine_desc* d, goicp_engine** ou
 
     goicp_engine* h = new goicp_engine();
     memset(&h->T, 0, sizeof h->T);
-    h->device = d->device_id; h->stream = nullptr; h->ev0 = h->ev1 = nullptr; h->stream_hi = nullptr; h->stream_bulk = nullptr; h->ev_wait = nullptr; h->wait_block = 0;
+    h->device = d->device_id; h->stream = nullptr; h->ev0 = h->ev1 = nullptr; h->stream_hi = nullptr; h->stream_bulk = nullptr; h->ev_wait = nullptr; h->wait_block = 0; h->upload_defer = 1;
     h->streamed = 0; h->stream_wgs = 0; h->stream_rot_wgs = 0; h->pinned = nullptr;
     h->d_heaps = nullptr; h->d_fpscratch = nullptr; h->heap_cap = 8192; h->heap_jobs = 0; h->fp_blocks = 0; h->d_heap_big = nullptr; h->heap_big_cap = 0;
     h->n_cubes = h->n_lookups = 0; h->kernel_ms = 0; h->max_pops = 200000000u;
@@ -3081,12 +3082,15 @@ extern "C" int goicp_engine_create(const goicp_engine_desc* d, goicp_engine** ou
     if (sparse) T.dist = (const float*)d->dt_dist_dev;        // adopted in place (owned by the caller's goicp_dtgpu handle)
     else { float* p_dist; CR(dev_upload(h, d->dt_dist, ncell, &p_dist)); T.dist = p_dist; }
     T.code = nullptr; T.lut = nullptr;
+    std::vector<float> lut;                     // (sources of deferred uploads live to the end of this function)
+    std::vector<int> occ_cells, occ_ptr(1, 0), occ_pts;
+    std::vector<uint16_t> occ_mask;
     {   // 2-byte coded copy of the grid for the gather stream (grids of 100^3 cells and more; GOICP_CODED=0 switches it off)
         const char* e = getenv("GOICP_CODED");
         if (d->S >= 100 && !(e && atoi(e) == 0)) {
             const long long full = 3ll * (d->S - 1) * (d->S - 1) + 1;
             const int lut_n = (int)std::min<long long>(full, 65535);
-            std::vector<float> lut((size_t)std::max(lut_n, LUT_LDS), 0.f);
+            lut.assign((size_t)std::max(lut_n, LUT_LDS), 0.f);
             for (int n = 0; n < lut_n; n++) lut[(size_t)n] = (float)((double)(float)sqrt((double)n) / d->scale);     // jly_3ddt.cpp:28,79,1003
             float* p_lut; CR(dev_upload(h, lut.data(), lut.size(), &p_lut));
             uint16_t* p_code; CR(dev_upload<uint16_t>(h, nullptr, ncell, &p_code));
@@ -3121,8 +3125,6 @@ extern "C" int goicp_engine_create(const goicp_engine_desc* d, goicp_engine** ou
         if (cls.size() > 16) { h->err = "more than 16 distinct colour codes"; CR(GOICP_ERR_ARG); }
         // compat mask per cell, resolving emptyCells -> cellPoints (reference jly_goicp.cpp:986-1000,1068-1092): the per-occupied-
         // cell masks are formed on the host (a few hundred cells), the S^3-sized gather through nearest_occ runs on the device
-        std::vector<int> occ_cells, occ_ptr(1, 0), occ_pts;
-        std::vector<uint16_t> occ_mask;
         auto add_cell = [&](int k, int col, int p0, int p1) {
             occ_cells.push_back(k);
             uint16_t m = 0;
@@ -3154,7 +3156,6 @@ extern "C" int goicp_engine_create(const goicp_engine_desc* d, goicp_engine** ou
         if (nOcc) hipLaunchKernelGGL(k_scatter_occ, dim3((nOcc + 255) / 256), dim3(256), 0, h->stream, p_cells, nOcc, p_occid);
         hipLaunchKernelGGL(k_build_cmask, dim3((unsigned)((ncell + 255) / 256)), dim3(256), 0, h->stream, p_near, p_occid, p_om, (unsigned long long)ncell, p_cm, p_occ);
         CRH(hipGetLastError());
-        CRH(hipStreamSynchronize(h->stream));
         {   // nearest_occ range check happened on the device (out-of-range entries resolve to "no occupied cell")
             T.cmask = p_cm;
         }
@@ -3171,7 +3172,6 @@ extern "C" int goicp_engine_create(const goicp_engine_desc* d, goicp_engine** ou
             if (T.nOcc > 0) {
                 hipLaunchKernelGGL(k_fpfh_table, dim3((unsigned)((ne + 255) / 256)), dim3(256), 0, h->stream, T, p_E);
                 CRH(hipGetLastError());
-                CRH(hipStreamSynchronize(h->stream));
             }
             T.fpE = p_E;
         }
@@ -3242,6 +3242,8 @@ extern "C" int goicp_engine_create(const goicp_engine_desc* d, goicp_engine** ou
             }
         }
     }
+    CRH(hipStreamSynchronize(h->stream));           // every deferred upload and set-up kernel
+    h->upload_defer = 0;
 #undef CR
 #undef CRH
     *out = h;
