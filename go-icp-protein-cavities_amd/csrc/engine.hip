@@ -417,7 +417,7 @@ struct TileShm {
 // DUAL = true (just-in-time, non-parity form): the tile is evaluated for TWO calls that share rotation and cubes -- the ub-call
 // (no rotation uncertainty) and an lb-call (radius row dual_rho) -- from ONE pass of gathers: results of the first in sh.ub2 / sh.lb2,
 // of the second in sh.ub / sh.lb. OuterBnB's two InnerBnB calls per child rotation (jly_goicp.cpp:768,861) read the same DT cells.
-template <int BLOCK, int PPT, bool OCT, int NT, bool JIT = false, bool DUAL = false>
+template <int BLOCK, int PPT, bool OCT, int NT, bool JIT = false, bool DUAL = false, bool XBIG = false /* JIT kernels: the parity_mode 2 instantiation (rows in HBM) */>
 __device__ __forceinline__ void sweep_tile(const DevTables& T, TileShm<BLOCK>& sh, const float (&px)[PPT], const float (&py)[PPT],
                                            const float (&pz)[PPT], const float (&pw)[PPT], const float (&prho)[PPT], bool use_rho,
                                            float* rbuf /* LDS, exact mode only */, bool row_mode = false /* !OCT: the cubes share y and z */,
@@ -521,7 +521,8 @@ __device__ __forceinline__ void sweep_tile(const DevTables& T, TileShm<BLOCK>& s
     // everything behind the gathers (selection + sums -> sh.ub / sh.lb) as one block, so that the fused form can run it twice on the same
     // distance values: first for the call without rotation uncertainty, then again after subtracting the radius of the other call
     auto finish = [&]() __attribute__((always_inline)) {      // (out of line the residual registers would go through scratch memory)
-    if ((BLOCK * PPT <= 1024 || JIT) && (JIT ? T.exact_big : T.exact) && T.doTrim) {
+    // (the just-in-time kernels carry the reference-order branches only in their parity_mode 2 instantiation: beside the fast path they cost it registers)
+    if ((JIT ? XBIG : (BLOCK * PPT <= 1024 && T.exact)) && T.doTrim) {
         // parity mode, trimmed: residual rows to LDS, one lane per cube runs the reference's selection (same swaps, same final
         // order), then the inlier sums are taken sequentially in float over that order -- bit-exact with jly_goicp.cpp:384-415
 #pragma unroll
@@ -563,7 +564,7 @@ __device__ __forceinline__ void sweep_tile(const DevTables& T, TileShm<BLOCK>& s
         __syncthreads();
         return;
     }
-    if ((JIT ? T.exact_big : T.exact) && !T.doTrim) {
+    if ((JIT ? XBIG : T.exact != 0) && !T.doTrim) {
         // reference order: float, sequential over the point index (bit-exact with jly_goicp.cpp:393-415). Every lane first
         // turns its residuals into the two addends (d*d and max(d-mtd,0)^2, or the norm-1 forms) in parallel; 16 lanes then
         // run the 16 sequential float sums (8 ub chains, 8 lb chains), one add per element. Skipping a term (e <= 0) and
@@ -2145,7 +2146,7 @@ __global__ __launch_bounds__(FR_SELECT_THREADS) void k_fr_select(FrCtx C, int ro
 // MODE 0: register-resident residuals, points fetched just in time (sweep_tile, BLOCK 512 x PPT points per lane, Nd <= 5120); an item is
 //         NT = 8 / ngroups children of the node (two items of 4 children each keep the residuals within 128 registers at 2 workgroups per CU)
 // MODE 1: streamed cloud (sweep_stream, trimmed or untrimmed)          MODE 2: streamed untrimmed cloud, one slice of the points per item
-template <int BLOCK, int PPT, int MODE, int NT>
+template <int BLOCK, int PPT, int MODE, int NT, bool XBIG = false>
 __device__ __forceinline__ void fr_expand_item(const DevTables& T, const FrCtx& C, TileShm<BLOCK>& sh, const FrItem item, float* rows, float* lutl) {
     const int tid = threadIdx.x;
     if (MODE == 0 && T.code) { for (int i = tid; i < LUT_LDS; i += BLOCK) lutl[i] = T.lut[i]; }   // (ordered by the barrier behind the cube set-up)
@@ -2167,7 +2168,7 @@ __device__ __forceinline__ void fr_expand_item(const DevTables& T, const FrCtx& 
         float px[PPT], py[PPT], pz[PPT], pw[PPT], prho[PPT];
 #pragma unroll
         for (int m = 0; m < PPT; m++) { px[m] = py[m] = pz[m] = pw[m] = prho[m] = 0.f; }
-        sweep_tile<BLOCK, PPT, true, NT, true>(T, sh, px, py, pz, pw, prho, level >= 0, rows, false, rot, rho, T.code ? lutl : nullptr);
+        sweep_tile<BLOCK, PPT, true, NT, true, false, XBIG>(T, sh, px, py, pz, pw, prho, level >= 0, rows, false, rot, rho, T.code ? lutl : nullptr);
         if (tid < NT) { out->ub[j0 + tid] = sh.ub[tid]; out->lb[j0 + tid] = sh.lb[tid]; }
         if (tid == 0 && item.split == 0) out->child_base = item.pad;
     } else if constexpr (MODE == 1) {
@@ -2183,7 +2184,7 @@ __device__ __forceinline__ void fr_expand_item(const DevTables& T, const FrCtx& 
     }
 }
 
-template <int BLOCK, int PPT, int MODE, int NT>
+template <int BLOCK, int PPT, int MODE, int NT, bool XBIG = false>
 __global__ __launch_bounds__(BLOCK, (MODE == 0 ? 4 : (BLOCK == 512 ? 4 : 1))) void k_fr_expand(DevTables T, FrCtx C, int round, int item0) {
     __shared__ TileShm<BLOCK> sh;
     __shared__ float lutl[MODE == 0 ? LUT_LDS : 1];
@@ -2192,14 +2193,14 @@ __global__ __launch_bounds__(BLOCK, (MODE == 0 ? 4 : (BLOCK == 512 ? 4 : 1))) vo
         // a residual-row scratch per resident workgroup: persistent workgroups walk the list
         float* rows = T.srows ? T.srows + (size_t)blockIdx.x * (T.exact_stream ? 2 : 1) * TC * T.NdP : nullptr;
         for (unsigned it = blockIdx.x; it < n; it += gridDim.x) {
-            fr_expand_item<BLOCK, PPT, MODE, NT>(T, C, sh, C.wl[it], rows, lutl);
+            fr_expand_item<BLOCK, PPT, MODE, NT, false>(T, C, sh, C.wl[it], rows, lutl);
             __syncthreads();
         }
     } else {
         // one item per workgroup (the host sizes the grid from the number of live searches). Inside a loop the compiler hoists the
         // per-lane point addresses of all PPT fetches out of it and the residuals no longer fit the 128 registers of 2 workgroups per CU.
         // (parity_mode 2: the launch goes out in chunks of T.xslots items, each workgroup with a slot of row scratch in HBM)
-        if (blockIdx.x + item0 < n) fr_expand_item<BLOCK, PPT, MODE, NT>(T, C, sh, C.wl[blockIdx.x + item0], T.exact_big ? T.xrows + (size_t)blockIdx.x * 2 * TC * T.NdP : nullptr, lutl);
+        if (blockIdx.x + item0 < n) fr_expand_item<BLOCK, PPT, MODE, NT, XBIG>(T, C, sh, C.wl[blockIdx.x + item0], XBIG ? T.xrows + (size_t)blockIdx.x * 2 * TC * T.NdP : nullptr, lutl);
     }
 }
 
@@ -2397,7 +2398,7 @@ __global__ __launch_bounds__(BLOCK) void k_gather_probe(DevTables T, const float
 //               with it, as OuterBnB's two InnerBnB calls per child rotation do (reference jly_goicp.cpp:768,861): one pass of gathers, two
 //               bound pairs per cube (sweep_tile<..., DUAL>). groups[y] = (slot, rot_level of the second call, output row of the first
 //               call, output row of the second).
-template <int PPT, bool DUAL>
+template <int PPT, bool DUAL, bool XBIG = false>
 __global__ __launch_bounds__(512, 4) void k_eval_cubes_geo(DevTables T, const float4* __restrict__ rot_all, const int4* __restrict__ groups,
                                                            const float* __restrict__ cubes, int n, float* __restrict__ ub_out, float* __restrict__ lb_out,
                                                            int tiles, int ngroups, int xcd_mode, int lin0 /* first workgroup of this launch (chunked launches of the exact mode) */) {
@@ -2421,7 +2422,7 @@ __global__ __launch_bounds__(512, 4) void k_eval_cubes_geo(DevTables T, const fl
         } else { const int l2 = lin + lin0; if (l2 >= tiles * ngroups) return; bx = l2 % tiles; by = l2 / tiles; }
     }
     // parity_mode 2: this workgroup's rows in HBM (the launch holds at most T.xslots workgroups)
-    float* xr = T.exact_big ? T.xrows + (size_t)blockIdx.x * 2 * TC * T.NdP : nullptr;
+    float* xr = XBIG ? T.xrows + (size_t)blockIdx.x * 2 * TC * T.NdP : nullptr;
     const int tid = threadIdx.x, Nd = T.Nd, base = bx * TC;
     if (T.code) { for (int i = tid; i < LUT_LDS; i += 512) lutl[i] = T.lut[i]; }     // (ordered by the barrier behind the cube set-up)
     const int4 g = groups[by];
@@ -2443,13 +2444,13 @@ __global__ __launch_bounds__(512, 4) void k_eval_cubes_geo(DevTables T, const fl
 #pragma unroll
     for (int m = 0; m < PPT; m++) { px[m] = py[m] = pz[m] = pw[m] = prho[m] = 0.f; }
     if constexpr (DUAL) {
-        sweep_tile<512, PPT, false, TC, true, true>(T, sh, px, py, pz, pw, prho, false, xr, row, rot, nullptr, T.code ? lutl : nullptr, rho);
+        sweep_tile<512, PPT, false, TC, true, true, XBIG>(T, sh, px, py, pz, pw, prho, false, xr, row, rot, nullptr, T.code ? lutl : nullptr, rho);
         if (tid < TC && base + tid < n) {
             ub_out[(size_t)g.z * n + base + tid] = sh.ub2[tid]; lb_out[(size_t)g.z * n + base + tid] = sh.lb2[tid];
             ub_out[(size_t)g.w * n + base + tid] = sh.ub[tid];  lb_out[(size_t)g.w * n + base + tid] = sh.lb[tid];
         }
     } else {
-        sweep_tile<512, PPT, false, TC, true, false>(T, sh, px, py, pz, pw, prho, g.y >= 0, xr, row, rot, rho, T.code ? lutl : nullptr);
+        sweep_tile<512, PPT, false, TC, true, false, XBIG>(T, sh, px, py, pz, pw, prho, g.y >= 0, xr, row, rot, rho, T.code ? lutl : nullptr);
         if (tid < TC && base + tid < n) { ub_out[(size_t)by * n + base + tid] = sh.ub[tid]; lb_out[(size_t)by * n + base + tid] = sh.lb[tid]; }
     }
 }
@@ -3369,8 +3370,8 @@ static int launch_eval(goicp_engine* h, int slot, int rot_level, const int2* gro
             const long long total = (long long)tiles * ng;
             for (long long l0 = 0; l0 < total; l0 += h->T.xslots) {
                 const unsigned cw = (unsigned)std::min<long long>(h->T.xslots, total - l0);
-#define CALLX(P2) do { if (dual) hipLaunchKernelGGL((k_eval_cubes_geo<P2, true>), dim3(cw), dim3(512), 0, h->stream, h->T, h->d_rot, gtab, (const float*)cubes_dev, n, (float*)ub_dev, (float*)lb_dev, tiles, ng, 0, (int)l0); \
-                       else hipLaunchKernelGGL((k_eval_cubes_geo<P2, false>), dim3(cw), dim3(512), 0, h->stream, h->T, h->d_rot, gtab, (const float*)cubes_dev, n, (float*)ub_dev, (float*)lb_dev, tiles, ng, 0, (int)l0); } while (0)
+#define CALLX(P2) do { if (dual) hipLaunchKernelGGL((k_eval_cubes_geo<P2, true, true>), dim3(cw), dim3(512), 0, h->stream, h->T, h->d_rot, gtab, (const float*)cubes_dev, n, (float*)ub_dev, (float*)lb_dev, tiles, ng, 0, (int)l0); \
+                       else hipLaunchKernelGGL((k_eval_cubes_geo<P2, false, true>), dim3(cw), dim3(512), 0, h->stream, h->T, h->d_rot, gtab, (const float*)cubes_dev, n, (float*)ub_dev, (float*)lb_dev, tiles, ng, 0, (int)l0); } while (0)
                 if (h->ppt == 2) CALLX(4); else if (h->ppt == 4) CALLX(8); else CALLX(10);
 #undef CALLX
             }
@@ -3425,7 +3426,7 @@ extern "C" const char* goicp_engine_eval_kernel_name(goicp_engine* h) {
     char buf[96];
     const bool jit = h->jit_eval != 0;
     if (h->streamed) snprintf(buf, sizeof buf, "k_eval_cubes_stream<%d>", h->T.Nd > 16384 ? 1024 : 512);
-    else if (jit && h->eval_nt == 8) snprintf(buf, sizeof buf, "k_eval_cubes_geo<%d,%s>", 2 * h->ppt, h->npairs > 0 ? "true" : "false");   // (true: the group table of the last multi-group call paired up)
+    else if (jit && h->eval_nt == 8) snprintf(buf, sizeof buf, "k_eval_cubes_geo<%d,%s,%s>", 2 * h->ppt, h->npairs > 0 ? "true" : "false", h->T.exact_big ? "true" : "false");   // (DUAL: the group table of the last multi-group call paired up; XBIG: parity_mode 2)
     else if (jit) snprintf(buf, sizeof buf, "k_eval_cubes<512,%d,%d,true>", 2 * h->ppt, h->eval_nt);
     else snprintf(buf, sizeof buf, "k_eval_cubes<%d,%d,8,false>", h->block, h->ppt);
     h->kernel_name = buf;
@@ -3604,7 +3605,7 @@ static void launch_fr_expand(goicp_engine* h, const FrCtx& C, int round, int max
     if (h->fr_mode == 1 && h->T.exact_big) {
         for (int i0 = 0; i0 < max_items; i0 += h->T.xslots) {
             const dim3 gc((unsigned)std::min(h->T.xslots, max_items - i0));
-#define FRC(B, P) hipLaunchKernelGGL((k_fr_expand<B, P, 0, 4>), gc, dim3(B), 0, h->stream, h->T, C, round, i0)
+#define FRC(B, P) hipLaunchKernelGGL((k_fr_expand<B, P, 0, 4, true>), gc, dim3(B), 0, h->stream, h->T, C, round, i0)
             if (h->fr_ppt == 4) FRC(512, 4); else if (h->fr_ppt == 8) FRC(512, 8); else FRC(512, 10);
 #undef FRC
         }

@@ -5,6 +5,9 @@ import os, sys, tempfile, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import numpy as np
+if os.environ.get("C4_WITH_TORCH"):      # the same batch inside a process that has PyTorch's HIP runtime up (as bench.py does)
+    import torch
+    torch.zeros(1, device="cuda")
 import goicp_amd
 from goicp_amd import driver, c4_batch
 
