@@ -472,10 +472,16 @@ __device__ __forceinline__ void sweep_tile(const DevTables& T, TileShm<BLOCK>& s
         }
         return oob;
     };
-    // diagnosis (GOICP_DBG & 64): cycle stamps of wave 0 / lane 0 of every 64th workgroup, summed into T.dbg_times[0..7]
+    // diagnosis (build with -DGOICP_TILE_STAMPS, run with GOICP_DBG & 64; tools/tile_phases.py): cycle stamps of wave 0 / lane 0 of every 64th
+    // workgroup, summed into T.dbg_times[0..7]. Compiled out by default: the stamp state costs the metric kernel registers it does not have.
+#ifdef GOICP_TILE_STAMPS
     const bool stamp = (T.dbg & 64) && T.dbg_times && tid == 0 && (blockIdx.x & 63) == 0;
     unsigned long long tl_ = stamp ? clock64() : 0ull;
 #define TSTAMP(k) do { if (stamp) { const unsigned long long now_ = clock64(); atomicAdd(&T.dbg_times[k], now_ - tl_); tl_ = now_; } } while (0)
+#else
+    constexpr bool stamp = false;
+#define TSTAMP(k) do { } while (0)
+#endif
     float4 pnext = make_float4(0.f, 0.f, 0.f, 0.f); float rnext = 0.f;
     if (JIT) { const int i0 = min(tid, Nd - 1); pnext = jit_rot[i0]; rnext = jit_rho ? jit_rho[i0] : 0.f; }
 #pragma unroll
@@ -2425,7 +2431,9 @@ __global__ __launch_bounds__(512, 4) void k_eval_cubes_geo(DevTables T, const fl
     float* xr = XBIG ? T.xrows + (size_t)blockIdx.x * 2 * TC * T.NdP : nullptr;
     const int tid = threadIdx.x, Nd = T.Nd, base = bx * TC;
     if (T.code) { for (int i = tid; i < LUT_LDS; i += 512) lutl[i] = T.lut[i]; }     // (ordered by the barrier behind the cube set-up)
-    const int4 g = groups[by];
+    int4 g = groups[by];
+    // (wave-uniform: kept in scalar registers, so that the output addresses formed from them at the end cost no vector registers in between)
+    g.x = __builtin_amdgcn_readfirstlane(g.x); g.y = __builtin_amdgcn_readfirstlane(g.y); g.z = __builtin_amdgcn_readfirstlane(g.z); g.w = __builtin_amdgcn_readfirstlane(g.w);
     const float4* __restrict__ rot = rot_all + (size_t)g.x * Nd;
     const float* __restrict__ rho = g.y >= 0 ? T.maxRotDis + (size_t)g.y * Nd : nullptr;
     if (tid < TC) {
