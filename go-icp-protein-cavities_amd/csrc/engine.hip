@@ -2601,10 +2601,19 @@ __global__ __launch_bounds__(1024) void k_icp_loop(DevTables T, const float* __r
     float* pm = pd + 3 * n;               // [3 n]  matched model point
     float* dsq = pm + 3 * n;              // [n]
     int* ids = reinterpret_cast<int*>(dsq + n);
+    float* dx = reinterpret_cast<float*>(ids + n);        // [3 n] data cloud
+    float* pbest = dx + 3 * n;            // [parts * n] partial searches: closest distance, its lowest index, how many points sit at it
+    int* pidx = reinterpret_cast<int*>(pbest + 1024);
+    int* pcnt = pidx + 1024;
     __shared__ double sR[9], st[3], smu_m[3], smu_d[3], sH[9];
     __shared__ float serr, serr_new;
     __shared__ int sties, sstop;
     for (int k = tid; k < 3 * Nm; k += blockDim.x) mx[k] = mxyz[k];
+    for (int k = tid; k < 3 * n; k += blockDim.x) dx[k] = T.dxyz[k];
+    // search layout: lane = (query, part of the model): every lane scans its part front to back, so "first point met at the closest distance"
+    // is the lowest index and no lane-to-lane reduction is needed; the parts of a query are merged in ascending order afterwards
+    const int parts = min(4, max(1, 1024 / n)), chunk = (Nm + parts - 1) / parts;
+    const int qi = tid % n, qp = tid / n;
     if (tid == 0) {
         for (int k = 0; k < 9; k++) sR[k] = st0.R[k];
         for (int k = 0; k < 3; k++) { st[k] = st0.t[k]; smu_m[k] = st0.mu_m[k]; smu_d[k] = st0.mu_d[k]; }
@@ -2612,44 +2621,74 @@ __global__ __launch_bounds__(1024) void k_icp_loop(DevTables T, const float* __r
     }
     __syncthreads();
     int iters = st0.iters, status = 0;
+    // diagnosis (GOICP_DBG & 32): cycles of lane 0 per phase into T.dbg_times[8..12] (search, sums, covariance, 3x3 algebra), [13] iterations
+    const bool timing = (T.dbg & 32) && T.dbg_times && tid == 0;
+    unsigned long long tph[4] = {0, 0, 0, 0}, tlast = timing ? clock64() : 0ull;
+#define ISTAMP(k) do { if (timing) { const unsigned long long now_ = clock64(); tph[k] += now_ - tlast; tlast = now_; } } while (0)
     for (;;) {
         if (iters >= max_iters) { status = 2; break; }
         iters++;
         // ---- correspondences: one wave per query, lanes over the model points (same arithmetic and reduction as k_icp_nn)
         const float r00 = (float)sR[0], r01 = (float)sR[1], r02 = (float)sR[2], r10 = (float)sR[3], r11 = (float)sR[4], r12 = (float)sR[5];
         const float r20 = (float)sR[6], r21 = (float)sR[7], r22 = (float)sR[8], t0 = (float)st[0], t1 = (float)st[1], t2 = (float)st[2];
-        for (int i = wave; i < n; i += NWV) {
-            const float d0 = T.dxyz[3 * i], d1 = T.dxyz[3 * i + 1], d2 = T.dxyz[3 * i + 2];
+        if (qp < parts) {
+            const float d0 = dx[3 * qi], d1 = dx[3 * qi + 1], d2 = dx[3 * qi + 2];
             const float q0 = r00 * d0 + r01 * d1 + r02 * d2 + t0;
             const float q1 = r10 * d0 + r11 * d1 + r12 * d2 + t1;
             const float q2 = r20 * d0 + r21 * d1 + r22 * d2 + t2;
             float best = INFINITY; int bi = 0x7fffffff, cnt = 0;
-            for (int m = lane; m < Nm; m += 64) {
+            const int m1 = min((qp + 1) * chunk, Nm);
+            int m = qp * chunk;
+            for (; m + 4 <= m1; m += 4) {                       // (all lanes of a part read the same model point: LDS broadcast)
+                float e[12];
+#pragma unroll
+                for (int k = 0; k < 12; k++) e[k] = mx[3 * m + k];
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    const float e0 = q0 - e[3 * k], e1 = q1 - e[3 * k + 1], e2 = q2 - e[3 * k + 2];
+                    const float d = e0 * e0 + e1 * e1 + e2 * e2;
+                    if (d < best) { best = d; bi = m + k; cnt = 1; }
+                    else if (d == best) cnt++;
+                }
+            }
+            for (; m < m1; m++) {
                 const float e0 = q0 - mx[3 * m], e1 = q1 - mx[3 * m + 1], e2 = q2 - mx[3 * m + 2];
                 const float d = e0 * e0 + e1 * e1 + e2 * e2;
                 if (d < best) { best = d; bi = m; cnt = 1; }
                 else if (d == best) cnt++;
             }
-#pragma unroll
-            for (int off = 32; off > 0; off >>= 1) {
-                const float ob = __shfl_down(best, off, 64); const int oi = __shfl_down(bi, off, 64); const int oc = __shfl_down(cnt, off, 64);
-                if (ob < best) { best = ob; bi = oi; cnt = oc; }
-                else if (ob == best) { cnt += oc; if (oi < bi) bi = oi; }
-            }
-            if (lane == 0) {
-                ids[i] = bi; dsq[i] = best;
-                pd[3 * i] = q0; pd[3 * i + 1] = q1; pd[3 * i + 2] = q2;
-                pm[3 * i] = mx[3 * bi]; pm[3 * i + 1] = mx[3 * bi + 1]; pm[3 * i + 2] = mx[3 * bi + 2];
-                if (cnt > 1) sties = 1;
-            }
+            pbest[tid] = best; pidx[tid] = bi; pcnt[tid] = cnt;
         }
         __syncthreads();
+        if (tid < n) {
+            float best = pbest[tid]; int bi = pidx[tid], cnt = pcnt[tid];
+            for (int p = 1; p < parts; p++) {                   // ascending parts: at equal distance the earlier (lower) index stays
+                const float ob = pbest[p * n + tid]; const int oi = pidx[p * n + tid], oc = pcnt[p * n + tid];
+                if (ob < best) { best = ob; bi = oi; cnt = oc; }
+                else if (ob == best) cnt += oc;
+            }
+            const int i = tid;
+            const float d0 = dx[3 * i], d1 = dx[3 * i + 1], d2 = dx[3 * i + 2];
+            ids[i] = bi; dsq[i] = best;
+            pd[3 * i] = r00 * d0 + r01 * d1 + r02 * d2 + t0; pd[3 * i + 1] = r10 * d0 + r11 * d1 + r12 * d2 + t1; pd[3 * i + 2] = r20 * d0 + r21 * d1 + r22 * d2 + t2;
+            pm[3 * i] = mx[3 * bi]; pm[3 * i + 1] = mx[3 * bi + 1]; pm[3 * i + 2] = mx[3 * bi + 2];
+            if (cnt > 1) sties = 1;
+        }
+        __syncthreads();
+        ISTAMP(0);
         if (sties) { status = 1; iters--; break; }            // this iteration belongs to the host (kd-tree order among tied model points)
         // ---- the seven running sums, each sequential over the point index on a lane of its own (jly_icp3d.hpp:256-276)
         if (tid < 6) {
             const float* src = tid < 3 ? pm + tid : pd + (tid - 3);
             double acc = tid < 3 ? smu_m[tid] : smu_d[tid - 3];
             int i = 0;
+            for (; i + 32 <= n; i += 32) {                     // 32 reads in flight, then the 32 dependent adds
+                float v[32];
+#pragma unroll
+                for (int q = 0; q < 32; q++) v[q] = src[3 * (i + q)];
+#pragma unroll
+                for (int q = 0; q < 32; q++) acc += (double)v[q];
+            }
             for (; i + 8 <= n; i += 8) {
                 float v[8];
 #pragma unroll
@@ -2662,6 +2701,13 @@ __global__ __launch_bounds__(1024) void k_icp_loop(DevTables T, const float* __r
         } else if (tid == 6) {
             float e = 0.f;
             int i = 0;
+            for (; i + 32 <= n; i += 32) {
+                float v[32];
+#pragma unroll
+                for (int q = 0; q < 32; q++) v[q] = dsq[i + q];
+#pragma unroll
+                for (int q = 0; q < 32; q++) e = (float)((double)e + (double)v[q]);
+            }
             for (; i + 8 <= n; i += 8) {
                 float v[8];
 #pragma unroll
@@ -2682,6 +2728,7 @@ __global__ __launch_bounds__(1024) void k_icp_loop(DevTables T, const float* __r
             }
         }
         __syncthreads();
+        ISTAMP(1);
         if (sstop) { status = 0; break; }
         // ---- covariance: nine sequential chains (jly_icp3d.hpp:281)
         if (tid < 9) {
@@ -2689,6 +2736,16 @@ __global__ __launch_bounds__(1024) void k_icp_loop(DevTables T, const float* __r
             const double ma = smu_d[a], mb = smu_m[b];
             double acc = 0;
             int i = 0;
+            for (; i + 16 <= n; i += 16) {                     // 32 reads in flight; the products do not wait for the running sum
+                float va[16], vb[16];
+#pragma unroll
+                for (int q = 0; q < 16; q++) { va[q] = pd[3 * (i + q) + a]; vb[q] = pm[3 * (i + q) + b]; }
+                double pr[16];
+#pragma unroll
+                for (int q = 0; q < 16; q++) pr[q] = ((double)va[q] - ma) * ((double)vb[q] - mb);
+#pragma unroll
+                for (int q = 0; q < 16; q++) acc += pr[q];
+            }
             for (; i + 8 <= n; i += 8) {
                 float va[8], vb[8];
 #pragma unroll
@@ -2700,6 +2757,7 @@ __global__ __launch_bounds__(1024) void k_icp_loop(DevTables T, const float* __r
             sH[tid] = acc;
         }
         __syncthreads();
+        ISTAMP(2);
         if (tid == 0) {
             double H[9], Rn[9], Rd[9], Rc[9], td[3], tc[3], t_[3], mum[3], mud[3];
             for (int k = 0; k < 9; k++) { H[k] = sH[k]; Rd[k] = sR[k]; }
@@ -2712,7 +2770,10 @@ __global__ __launch_bounds__(1024) void k_icp_loop(DevTables T, const float* __r
             for (int k = 0; k < 3; k++) st[k] = tc[k];
         }
         __syncthreads();
+        ISTAMP(3);
     }
+    if (timing) { for (int k = 0; k < 4; k++) atomicAdd(&T.dbg_times[8 + k], tph[k]); atomicAdd(&T.dbg_times[12], (unsigned long long)(iters - st0.iters)); }
+#undef ISTAMP
     __syncthreads();
     for (int i = tid; i < n; i += blockDim.x) { ids_out[i] = ids[i]; dsq_out[i] = dsq[i]; }
     if (tid == 0) {
@@ -3773,10 +3834,11 @@ static_assert(sizeof(IcpState) == sizeof(goicp_icp_state), "goicp_icp_state");
 extern "C" int goicp_engine_icp_loop(goicp_engine* h, goicp_icp_state* state, float err_diff, int max_iters, int32_t* id_model, float* dist_sq) {
     if (!h || !state || !id_model || !dist_sq || max_iters < 0) return GOICP_ERR_ARG;
     const size_t n = (size_t)h->T.Nd, nm = (size_t)h->T.Nm;
-    const size_t lds = (3 * nm + 8 * n) * sizeof(float);
+    const size_t lds = (3 * nm + 11 * n + 3 * 1024) * sizeof(float);
     // cavity class only: untrimmed, everything in one workgroup's LDS, results through the pinned buffer
-    if (h->T.doTrim || h->T.Nm <= 0 || n > 1024 || nm > 2048 || lds > 60 * 1024 || !h->pinned || sizeof(IcpState) + 8 * n + 64 > PINNED_BYTES) return GOICP_ERR_ARG;
+    if (h->T.doTrim || h->T.Nm <= 0 || n > 1024 || nm > 2048 || lds > 120 * 1024 || !h->pinned || sizeof(IcpState) + 8 * n + 64 > PINNED_BYTES) return GOICP_ERR_ARG;
     HIPCHK(h, hipSetDevice(h->device));
+    if (lds > 48 * 1024) HIPCHK(h, set_max_dyn_lds(reinterpret_cast<const void*>(&k_icp_loop)));
     IcpState st0; memcpy(&st0, state, sizeof st0);
     IcpState* po = (IcpState*)h->pinned;
     int* pid = (int*)((char*)h->pinned + ((sizeof(IcpState) + 63) & ~(size_t)63)); float* pdq = (float*)(pid + n);
