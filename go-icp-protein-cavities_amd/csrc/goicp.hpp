@@ -151,6 +151,7 @@ private:
     std::vector<int32_t> icp_id_data_, icp_id_model_, opt_id_data_, opt_id_model_;
     std::vector<double> icp_dis_;
     std::vector<uint32_t> sort_key_, sort_a_, sort_b_;
+    bool host_compat_ = false;             // geometric runs on a host-built grid: the compatibility count is taken on the host (no cell tables on the device)
     KdOrder kd_order_;                     // the reference kd-tree's visiting order, built on the first exact distance tie
     float OuterBnB();                      // reference jly_goicp.cpp:582-876
     float icp_run(Matrix& R, Matrix& t);   // reference jly_icp3d.hpp:197-311 (1-NN on the device)

@@ -313,12 +313,16 @@ void GoICP::Initialize() {
     goicp_engine_desc d;
     std::memset(&d, 0, sizeof d);
     d.S = dt.SIZE; d.xMin = dt.xMin; d.yMin = dt.yMin; d.zMin = dt.zMin; d.scale = dt.scale;
+    // The cell tables feed the penalty terms; without them (geometric error) the only consumer is the per-point compatibility test behind the
+    // "Compatibilities" count of the result, which the host then does itself on its own copy of the tables (updateCompatibilities): a 300^3
+    // nearest-cell map is 108 MB of upload and 270 MB of device tables saved per registration.
+    host_compat_ = !dt.gpu && !(regularization > 0) && !(regularizationFPFH > 0);
     if (dt.gpu) {               // device-resident grid: adopted in place, sparse cell tables
         d.dt_dist_dev = goicp_dtgpu_dist(dt.gpu); d.nearest_occ_dev = goicp_dtgpu_nearest(dt.gpu);
         d.n_occ = (int32_t)dt.occ_cells.size(); d.occ_cells = dt.occ_cells.data(); d.occ_color = dt.occ_color.data(); d.occ_ptr = dt.occ_ptr.data(); d.cell_idx = dt.cell_idx.data();
     } else {
         d.dt_dist = dt.dist.data();
-        d.nearest_occ = dt.nearest.data(); d.cell_color = dt.cell_color.data(); d.cell_ptr = dt.cell_ptr.data(); d.cell_idx = dt.cell_idx.data();
+        if (!host_compat_) { d.nearest_occ = dt.nearest.data(); d.cell_color = dt.cell_color.data(); d.cell_ptr = dt.cell_ptr.data(); d.cell_idx = dt.cell_idx.data(); }
     }
     d.Nm = Nm; d.model_xyz = mxyz.data(); d.model_color = mcol.data(); d.model_fpfh = need_fpfh ? mf.data() : nullptr;
     d.Nd = Nd; d.data_xyz = dxyz.data(); d.data_color = dcol.data(); d.data_fpfh = need_fpfh ? df.data() : nullptr;
@@ -344,6 +348,31 @@ int GoICP::countCompatibilities(const std::vector<int32_t>& idd, const std::vect
 int GoICP::updateCompatibilities() {
     double R[9], t[3];
     for (int i = 0; i < 3; i++) { for (int j = 0; j < 3; j++) R[3 * i + j] = optR.val[i][j]; t[i] = optT.val[i][0]; }
+    if (host_compat_) {
+        // checkCompatibility per point (reference jly_goicp.cpp:937-946, 974-1000) on the host tables: (float)(R*p + t), the clamped cell, its nearest
+        // occupied cell, and the colour test of that cell -- a mixed cell accepts the colours of its points, a uniform one its own (known) colour
+        const int S = dt.SIZE;
+        const size_t ncell = (size_t)S * S * S;
+        auto cell_of = [&](float v, double mn) { return (int)(((double)v - mn) * dt.scale + 0.5); };
+        int bad = 0;
+        for (int i = 0; i < Nd; i++) {
+            const float px = pData[i].x, py = pData[i].y, pz = pData[i].z;
+            const float x = (float)(R[0] * px + R[1] * py + R[2] * pz + t[0]);
+            const float y = (float)(R[3] * px + R[4] * py + R[5] * pz + t[1]);
+            const float z = (float)(R[6] * px + R[7] * py + R[8] * pz + t[2]);
+            int cx = cell_of(x, dt.xMin), cy = cell_of(y, dt.yMin), cz = cell_of(z, dt.zMin);
+            cx = cx < 0 ? 0 : (cx >= S ? S - 1 : cx); cy = cy < 0 ? 0 : (cy >= S ? S - 1 : cy); cz = cz < 0 ? 0 : (cz >= S ? S - 1 : cz);
+            const int32_t nk = dt.nearest[((size_t)cz * S + cy) * S + cx];
+            bool ok = false;
+            if (nk >= 0 && (size_t)nk < ncell) {
+                const int col = dt.cell_color[nk], c = pData[i].c;
+                if (col == -1) { for (int q = dt.cell_ptr[nk]; q < dt.cell_ptr[nk + 1] && !ok; q++) ok = pModel[dt.cell_idx[q]].c == c; }
+                else if (col != -2 && known_prop(col)) ok = c == col;
+            }
+            if (!ok) bad++;
+        }
+        return bad;
+    }
     std::vector<float> dist(Nd); std::vector<int32_t> ok(Nd);
     status = goicp_engine_point_eval(eng_, R, t, dist.data(), ok.data());
     int bad = 0;

@@ -765,3 +765,17 @@ def test_c3_headline_pair_is_bit_exact_in_parity_mode_2():
     for (a, x), (b, y) in zip(out["trace"], G["trace"]):
         assert abs(x - y) <= 6e-6 * abs(y)            # (the known answer holds the reference's 6-digit progress lines)
     g.close()
+
+
+@pytest.mark.parametrize("S", [20, 50])
+def test_compatibility_count_without_penalty_terms_matches_the_oracle(S):
+    """Geometric error only (regularization 0) on coloured cavity clouds: the engine then carries no cell tables and the "Compatibilities" count of
+    the result is taken on the host tables (GoICP::updateCompatibilities); it must equal the oracle's, as must the whole registration."""
+    P = load_clouds("pair1")
+    v, _ = cfg_vector(regularization=0.0, distTransSize=S)
+    o = oracle_for(P, v); want = o.register()
+    g = goicp_amd.GoICP(v); g.set_clouds(P["t"], P["s"], P["tc"], P["sc"], P["tf"], P["sf"]); g.build_dt()
+    got = g.register()
+    assert float(got["error"]) == float(want["error"]) and got["comp"] == want["comp"], (got["error"], want["error"], got["comp"], want["comp"])
+    assert np.abs(got["R"] - want["R"]).max() < 1e-9 and np.abs(got["t"] - want["t"]).max() < 1e-9
+    g.close()
