@@ -2811,8 +2811,6 @@ struct goicp_engine {
     int block, ppt; size_t dyn_lds; size_t dyn_lds_bnb; int heap_lds_nodes; int rbuf_floats; int fp_lds;
     int resident_jobs;                       // search workgroups resident at once (CUs x occupancy of the chosen k_inner_bnb)
     int streamed; size_t stream_wgs, stream_rot_wgs;   // streaming path: scratch sized for this many resident workgroups (rows / rotated clouds)
-    int eval_pad;                            // extra dynamic LDS bytes of the just-in-time sweep kernel (experiment knob GOICP_EVAL_PAD: 16384 leaves one workgroup per CU)
-    int eval_nt;                             // cubes per workgroup tile of the just-in-time sweep kernel (experiment knob GOICP_EVAL_NT: 8, 4 or 2)
     int last_fused;                          // the last goicp_engine_eval_cubes* call evaluated its (no radius, radius) group pairs from one pass of gathers
     int xcd_mode;                            // workgroup -> (group, tile) map of k_eval_cubes_geo (GOICP_XCD, read once per engine)
     int jit_eval;                            // clouds of 1025..5120 points without penalty terms: the just-in-time sweep kernels (GOICP_JIT=0 disables; read once per engine)
@@ -3110,8 +3108,6 @@ extern "C" int goicp_engine_create(const goicp_engine_desc* d, goicp_engine** ou
     h->streamed = 0; h->stream_wgs = 0; h->stream_rot_wgs = 0; h->pinned = nullptr;
     h->d_heaps = nullptr; h->d_fpscratch = nullptr; h->heap_cap = 8192; h->heap_jobs = 0; h->fp_blocks = 0; h->d_heap_big = nullptr; h->heap_big_cap = 0;
     h->n_cubes = h->n_lookups = 0; h->kernel_ms = 0; h->max_pops = 200000000u;
-    { const char* e = getenv("GOICP_EVAL_NT"); h->eval_nt = (e && (atoi(e) == 4 || atoi(e) == 2)) ? atoi(e) : 8; }
-    { const char* e = getenv("GOICP_EVAL_PAD"); h->eval_pad = e ? std::max(0, std::min(atoi(e), 60000)) : 0; }
     h->code_escapes = 0; h->last_fused = 0;
     h->fr_mode = 0; h->fr_st = nullptr; h->fr_heaps = nullptr; h->fr_exps = nullptr; h->fr_wl = nullptr; h->fr_cnt = nullptr; h->fr_parts = nullptr; h->fr_srot = nullptr; h->fr_results = nullptr;
     h->fr_jobs = 0; h->fr_cap_nodes = 0; h->fr_cap_exps = 0; h->fr_wl_cap = 0; h->fr_rounds = 0; h->fr_spec_cubes = 0;
@@ -3419,8 +3415,7 @@ static int launch_eval(goicp_engine* h, int slot, int rot_level, const int2* gro
     // clouds of 1025..5120 points without penalty terms: 512 lanes x twice the points, the points fetched just in time instead of
     // held in registers -> 128 VGPRs, two workgroups per CU, one gathering while the other selects (3.89 -> 3.52 ms at C3)
     const bool jit = h->jit_eval != 0;
-#define CALLJ(P2) hipLaunchKernelGGL((k_eval_cubes<512, P2, TC, true>), dim3(tiles, ngroups), dim3(512), h->dyn_lds + (size_t)h->eval_pad, h->stream, h->T, h->d_rot, slot, rot_level, groups_dev, (const float*)cubes_dev, n, (float*)ub_dev, (float*)lb_dev, h->d_fpscratch)
-    if (jit && h->eval_nt == 8) {
+    if (jit) {
         // geometric just-in-time sweep: its own kernel; group pairs (no radius / radius, same slot) of a multi-group call fused when all pair up
         const bool dual = groups_dev == h->d_groups && h->npairs > 0 && h->npairs * 2 == ngroups;
         h->last_fused = dual ? 1 : 0;
@@ -3450,15 +3445,7 @@ static int launch_eval(goicp_engine* h, int slot, int rot_level, const int2* gro
         h->n_cubes += (uint64_t)n * ngroups; h->n_lookups += (uint64_t)n * ngroups * h->T.Nd;
         return GOICP_OK;
     }
-#define CALLJN(P2, NTT) hipLaunchKernelGGL((k_eval_cubes<512, P2, NTT, true>), dim3((n + NTT - 1) / NTT, ngroups), dim3(512), h->dyn_lds, h->stream, h->T, h->d_rot, slot, rot_level, groups_dev, (const float*)cubes_dev, n, (float*)ub_dev, (float*)lb_dev, h->d_fpscratch)
-    if (jit && h->ppt == 2) CALLJ(4);
-    else if (jit && h->ppt == 4) CALLJ(8);
-    else if (jit && h->ppt == 5 && h->eval_nt == 4) CALLJN(10, 4);
-    else if (jit && h->ppt == 5 && h->eval_nt == 2) CALLJN(10, 2);
-    else if (jit && h->ppt == 5) CALLJ(10);
-    else DISPATCH_GEOM(h, CALL);
-#undef CALLJN
-#undef CALLJ
+    DISPATCH_GEOM(h, CALL);
 #undef CALL
     HIPCHK(h, hipGetLastError());
     h->n_cubes += (uint64_t)n * ngroups; h->n_lookups += (uint64_t)n * ngroups * h->T.Nd;
@@ -3495,8 +3482,7 @@ extern "C" const char* goicp_engine_eval_kernel_name(goicp_engine* h) {
     char buf[96];
     const bool jit = h->jit_eval != 0;
     if (h->streamed) snprintf(buf, sizeof buf, "k_eval_cubes_stream<%d>", h->T.Nd > 16384 ? 1024 : 512);
-    else if (jit && h->eval_nt == 8) snprintf(buf, sizeof buf, "k_eval_cubes_geo<%d,%s,%s>", 2 * h->ppt, h->npairs > 0 ? "true" : "false", h->T.exact_big ? "true" : "false");   // (DUAL: the group table of the last multi-group call paired up; XBIG: parity_mode 2)
-    else if (jit) snprintf(buf, sizeof buf, "k_eval_cubes<512,%d,%d,true>", 2 * h->ppt, h->eval_nt);
+    else if (jit) snprintf(buf, sizeof buf, "k_eval_cubes_geo<%d,%s,%s>", 2 * h->ppt, h->npairs > 0 ? "true" : "false", h->T.exact_big ? "true" : "false");   // (DUAL: the group table of the last multi-group call paired up; XBIG: parity_mode 2)
     else snprintf(buf, sizeof buf, "k_eval_cubes<%d,%d,8,false>", h->block, h->ppt);
     h->kernel_name = buf;
     return h->kernel_name.c_str();
