@@ -3020,6 +3020,7 @@ extern "C" void goicp_engine_destroy(goicp_engine* h) {
     do {                                                                     \
         if (h->block == 256 && h->ppt == 1) { CALL(256, 1); }                \
         else if (h->block == 256 && h->ppt == 2) { CALL(256, 2); }           \
+        else if (h->block == 512 && h->ppt == 1) { CALL(512, 1); }           \
         else if (h->block == 1024 && h->ppt == 1) { CALL(1024, 1); }         \
         else if (h->block == 1024 && h->ppt == 2) { CALL(1024, 2); }         \
         else if (h->block == 1024 && h->ppt == 4) { CALL(1024, 4); }         \
@@ -3057,6 +3058,9 @@ static void pick_geometry(goicp_engine* h) {
     // the streamed sweep does 109-118 G lookups/s there, so geometric runs switch to it early. Penalty runs keep registers up to 8192.
     h->streamed = Nd > 8192 || (Nd > 5120 && !h->T.use_compat && !h->T.use_fpfh);
     if (h->streamed) { h->block = 1024; h->ppt = 1; }          // cloud streamed from HBM per tile (sweep_stream)
+    // trimmed runs in parity mode: one wave per cube row runs the reference's selection, and at 256 lanes a wave would take two rows one after the
+    // other -- 512 lanes give each of the 8 rows a wave of its own (one search per CU instead of two, each pop about twice as fast)
+    else if (h->T.exact && h->T.doTrim && Nd <= 512 && !env_is_zero("GOICP_TRIM512")) { h->block = 512; h->ppt = 1; }
     else if (Nd <= 256) { h->block = 256; h->ppt = 1; }
     else if (Nd <= 512) { h->block = 256; h->ppt = 2; }
     else if (Nd <= 1024) { h->block = 1024; h->ppt = 1; }
