@@ -2087,11 +2087,12 @@ __global__ __launch_bounds__(FR_SELECT_THREADS) void k_fr_select(FrCtx C, int ro
         // a node whose bound already meets the stop test can never be expanded (the incumbent only falls): not worth a sweep
         const bool want = have && me.exp < 0 && !(st.optErrorT - me.lb < jb.SSEThresh);
         int rank = 0;
-        for (int m = 0; m < 63; m++) {
-            const float olb = __shfl(me.lb, m, 64), ow = __shfl(me.w, m, 64);
-            const int owant = __shfl((int)want, m, 64);
+        // (only the wanted slots count, and their keys come through v_readlane -- a scalar lane index -- instead of 3 x 63 trips through the LDS crossbar)
+        for (unsigned long long wm = __ballot(want); wm; wm &= wm - 1) {
+            const int m = __ffsll((long long)wm) - 1;
+            const float olb = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(me.lb), m)), ow = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(me.w), m));
             const bool better = olb != me.lb ? olb < me.lb : (ow != me.w ? ow > me.w : m < lane);
-            rank += (owant && better) ? 1 : 0;
+            rank += better ? 1 : 0;
         }
         const int slots = depth >= 2 ? 9 : 1;                          // expansion records per chosen node
         const bool sel = want && rank < K && st.ne + (rank + 1) * slots <= C.exp_cap;
