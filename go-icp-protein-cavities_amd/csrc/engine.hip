@@ -1477,79 +1477,47 @@ __device__ __forceinline__ void sweep_stream(const DevTables& T, TileShm<BLOCK>&
         su[j] += (double)tu;
         if (e > 0.f) sl[j] += (double)tl;
     };
-    // the next chunk's point is fetched while the current chunk's gathers are in flight
-    const int pbeg = PARTIAL ? p0 : 0;
-    float4 pnext = rot[min(pbeg + tid, Nd - 1)];
-    float rnext = rho_row ? rho_row[min(pbeg + tid, Nd - 1)] : 0.f;
-    for (int b = pbeg; b < Nd; b += BLOCK) {
-        const int i = b + tid;
-        const bool valid = i < Nd;
-        const float4 p = pnext;
-        const float rh = rnext;
-        if (b + BLOCK < Nd) { const int in = min(i + BLOCK, Nd - 1); pnext = rot[in]; if (rho_row) rnext = rho_row[in]; }
-        unsigned idx[TC]; unsigned oob = 0u;
-        if (OCT) {
-            int rx[2], ry[2], rz[2];
+    // (only trimmed, order-free runs get here.) Pass 0, lane = (point, cube) as in the untrimmed sweep above: the residual rows go to HBM, every
+    // lane keeps the largest residual of its cube (the window of the histogram pass that follows, which reads the rows back lane = point).
+    {
+        constexpr int PB = BLOCK / 8, U = 8;
+        const int j = tid & 7, q = tid >> 3;
+        const float cx = sh.cen[j][0], cy = sh.cen[j][1], cz = sh.cen[j][2];
+        unsigned mx1 = 0u;
+        for (int b = 0; b < Nd; b += PB * U) {
+            unsigned idx[U]; float w[U], rh[U], ext[U]; bool valid[U];
 #pragma unroll
-            for (int q = 0; q < 2; q++) {
-                rx[q] = cell_of(p.x + sh.cen[q][0], T.xMin, T.scale);
-                ry[q] = cell_of(p.y + sh.cen[2 * q][1], T.yMin, T.scale);
-                rz[q] = cell_of(p.z + sh.cen[4 * q][2], T.zMin, T.scale);
+            for (int k = 0; k < U; k++) {
+                const int i = b + q + k * PB;
+                valid[k] = i < Nd;
+                const float4 p = rot[min(i, Nd - 1)];
+                rh[k] = rho_row ? rho_row[min(i, Nd - 1)] : 0.f;
+                const int x = cell_of(p.x + cx, T.xMin, T.scale), y = cell_of(p.y + cy, T.yMin, T.scale), z = cell_of(p.z + cz, T.zMin, T.scale);
+                idx[k] = (unsigned)((clamp_cell(z, S) * S + clamp_cell(y, S)) * S + clamp_cell(x, S));
+                ext[k] = dt_ext_raw(x, y, z, S);
+                w[k] = p.w;
+            }
+            float v[U];
+            if (T.code) {
+                unsigned c[U];
+#pragma unroll
+                for (int k = 0; k < U; k++) c[k] = T.code[idx[k]];
+#pragma unroll
+                for (int k = 0; k < U; k++) v[k] = dt_decode(T, idx[k], c[k], nullptr);
+            } else {
+#pragma unroll
+                for (int k = 0; k < U; k++) v[k] = T.dist[idx[k]];
             }
 #pragma unroll
-            for (int j = 0; j < TC; j++) {
-                const int x = rx[j & 1], y = ry[j >> 1 & 1], z = rz[j >> 2 & 1];
-                idx[j] = (unsigned)((clamp_cell(z, S) * S + clamp_cell(y, S)) * S + clamp_cell(x, S));
-                oob |= ((((unsigned)x >= (unsigned)S) | ((unsigned)y >= (unsigned)S) | ((unsigned)z >= (unsigned)S)) ? 1u : 0u) << j;
-            }
-        } else if (row_mode) {
-            const int y = cell_of(p.y + sh.cen[0][1], T.yMin, T.scale), z = cell_of(p.z + sh.cen[0][2], T.zMin, T.scale);
-            const int rowbase = (clamp_cell(z, S) * S + clamp_cell(y, S)) * S;
-            const unsigned yz_out = (((unsigned)y >= (unsigned)S) | ((unsigned)z >= (unsigned)S)) ? 1u : 0u;
-#pragma unroll
-            for (int j = 0; j < TC; j++) {
-                const int x = cell_of(p.x + sh.cen[j][0], T.xMin, T.scale);
-                idx[j] = (unsigned)(rowbase + clamp_cell(x, S));
-                oob |= (yz_out | (((unsigned)x >= (unsigned)S) ? 1u : 0u)) << j;
-            }
-        } else {
-#pragma unroll
-            for (int j = 0; j < TC; j++) {
-                const int x = cell_of(p.x + sh.cen[j][0], T.xMin, T.scale), y = cell_of(p.y + sh.cen[j][1], T.yMin, T.scale), z = cell_of(p.z + sh.cen[j][2], T.zMin, T.scale);
-                idx[j] = (unsigned)((clamp_cell(z, S) * S + clamp_cell(y, S)) * S + clamp_cell(x, S));
-                oob |= ((((unsigned)x >= (unsigned)S) | ((unsigned)y >= (unsigned)S) | ((unsigned)z >= (unsigned)S)) ? 1u : 0u) << j;
-            }
-        }
-        float v[TC];
-        if (T.code) {
-            unsigned c[TC];
-#pragma unroll
-            for (int j = 0; j < TC; j++) c[j] = T.code[idx[j]];
-#pragma unroll
-            for (int j = 0; j < TC; j++) v[j] = dt_decode(T, idx[j], c[j], nullptr);
-        } else {
-#pragma unroll
-            for (int j = 0; j < TC; j++) v[j] = T.dist[idx[j]];
-        }
-        if (__any((int)oob)) {
-#pragma unroll
-            for (int j = 0; j < TC; j++) {
-                if ((oob >> j) & 1u) {
-                    float ext; (void)dt_index(T, p.x + sh.cen[j][0], p.y + sh.cen[j][1], p.z + sh.cen[j][2], ext);
-                    v[j] = dt_finish(T, v[j], ext);
-                }
+            for (int k = 0; k < U; k++) {
+                float d = w[k] * dt_finish(T, v[k], ext[k]);
+                if (rho_row) d -= rh[k];
+                if (d < 0.f) d = 0.f;
+                if (valid[k]) { rows[(size_t)j * NdP + b + q + k * PB] = d; mx1 = max(mx1, __float_as_uint(d)); }
             }
         }
 #pragma unroll
-        for (int j = 0; j < TC; j++) {
-            float d = p.w * v[j];
-            if (rho_row) d -= rh;
-            if (d < 0.f) d = 0.f;
-            if (valid) {
-                if (trim) { rows[(size_t)j * NdP + i] = d; mx[j] = max(mx[j], __float_as_uint(d)); }
-                else add_terms(j, d);
-            }
-        }
+        for (int jj = 0; jj < TC; jj++) mx[jj] = jj == j ? mx1 : 0u;
     }
     unsigned thr[TC]; int below[TC];
 #pragma unroll
