@@ -2422,13 +2422,17 @@ __global__ __launch_bounds__(512, 4) void k_eval_cubes_geo(DevTables T, const fl
     for (int m = 0; m < PPT; m++) { px[m] = py[m] = pz[m] = pw[m] = prho[m] = 0.f; }
     if constexpr (DUAL) {
         sweep_tile<512, PPT, false, TC, true, true, XBIG>(T, sh, px, py, pz, pw, prho, false, xr, row, rot, nullptr, T.code ? lutl : nullptr, rho);
-        if (tid < TC && base + tid < n) {
-            ub_out[(size_t)g.z * n + base + tid] = sh.ub2[tid]; lb_out[(size_t)g.z * n + base + tid] = sh.lb2[tid];
-            ub_out[(size_t)g.w * n + base + tid] = sh.ub[tid];  lb_out[(size_t)g.w * n + base + tid] = sh.lb[tid];
+        // (results out by lane id, from every wave alike -- identical values to identical addresses: the workitem id would have to survive the
+        // whole sweep in a register the kernel does not have, i.e. in scratch)
+        const int ol = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+        if (ol < TC && base + ol < n) {
+            ub_out[(size_t)g.z * n + base + ol] = sh.ub2[ol]; lb_out[(size_t)g.z * n + base + ol] = sh.lb2[ol];
+            ub_out[(size_t)g.w * n + base + ol] = sh.ub[ol];  lb_out[(size_t)g.w * n + base + ol] = sh.lb[ol];
         }
     } else {
         sweep_tile<512, PPT, false, TC, true, false, XBIG>(T, sh, px, py, pz, pw, prho, g.y >= 0, xr, row, rot, rho, T.code ? lutl : nullptr);
-        if (tid < TC && base + tid < n) { ub_out[(size_t)by * n + base + tid] = sh.ub[tid]; lb_out[(size_t)by * n + base + tid] = sh.lb[tid]; }
+        const int ol = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+        if (ol < TC && base + ol < n) { ub_out[(size_t)by * n + base + ol] = sh.ub[ol]; lb_out[(size_t)by * n + base + ol] = sh.lb[ol]; }
     }
 }
 
