@@ -1,6 +1,7 @@
 """Randomised parity campaign (run on the GPU box): GoICP::Register() on the HIP path vs the plain-C oracle on seeded cavity-like
 pairs over a cycle of configurations. Prints one line per pair and a summary; exit status 1 on any mismatch.
-Test infrastructure (uses oracle/): python tools/parity_campaign.py [n_pairs]"""
+Test infrastructure (uses oracle/): python tools/parity_campaign.py [n_pairs] [first_pair]   (the pair number seeds the pair, so a second
+campaign with first_pair = the first one's n_pairs covers fresh clouds)"""
 import os, sys, time
 from concurrent.futures import ThreadPoolExecutor
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -43,9 +44,10 @@ def one(k):
 
 if __name__ == "__main__":
     npairs = int(sys.argv[1]) if len(sys.argv) > 1 else 40
+    first = int(sys.argv[2]) if len(sys.argv) > 2 else 0
     bad = 0
     with ThreadPoolExecutor(max_workers=12) as ex:
-        for k, name, n, ok, eo, eg, tc, tg, cev in ex.map(one, range(npairs)):
+        for k, name, n, ok, eo, eg, tc, tg, cev in ex.map(one, range(first, first + npairs)):
             print("pair %3d %-9s N=%3d %s oracle %.6g gpu %.6g  cpu %.2fs gpu %.3fs cube_evals %d" % (k, name, n, "SKIP" if ok is None else ("OK  " if ok else "MISMATCH"), eo, eg, tc, tg, cev), flush=True)
             bad += 1 if ok is False else 0
     print("pairs %d mismatches %d" % (npairs, bad))
