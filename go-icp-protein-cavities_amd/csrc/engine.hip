@@ -278,7 +278,23 @@ __device__ __forceinline__ void wave_intro_select(float* d, int* idx, int n, int
         n_rounds++;
         if (e - s <= 5) {
             const unsigned long long t0 = st ? clock64() : 0ull;
-            if (lane == 0) { float t; for (int i = s + 1; i <= e; i++) for (int j = i; j > s && d[j - 1] > d[j]; j--) { t = d[j - 1]; d[j - 1] = d[j]; d[j] = t; } }
+            // (the reference's insertion sort of the last <= 6 elements: the sorted arrangement is a function of the values alone, so the
+            // elements are fetched together, sorted in registers and written back by lane 0 instead of ~15 dependent round trips)
+            {
+                const int cnt = e - s + 1;
+                float w[6];
+#pragma unroll
+                for (int q = 0; q < 6; q++) w[q] = q < cnt ? d[s + q] : __builtin_inff();
+#pragma unroll
+                for (int i = 1; i < 6; i++) {
+#pragma unroll
+                    for (int j = i; j > 0; j--) { const float a = w[j - 1], b = w[j]; const bool sw = a > b; w[j - 1] = sw ? b : a; w[j] = sw ? a : b; }
+                }
+                if (lane == 0) {
+#pragma unroll
+                    for (int q = 0; q < 6; q++) if (q < cnt) d[s + q] = w[q];
+                }
+            }
             if (st) c_ins += clock64() - t0;
             break;
         }
@@ -301,9 +317,10 @@ __device__ __forceinline__ void wave_intro_select(float* d, int* idx, int n, int
             pi = tmp;
             piv = d[pi]; dfront = d[s];
         }
-        (MEM ? wave_sync_mem() : wave_sync_lds());
+        // pivot to the front. No hand-off is needed around it: the three reads above have returned (the pivot's index is computed from
+        // them), the slices below never read d[s], and the one slot they could see too early (d[pi]) is patched in registers.
+        if (!quick) (MEM ? wave_sync_mem() : wave_sync_lds());
         if (pi != s && lane == 0) { d[pi] = dfront; d[s] = piv; }
-        (MEM ? wave_sync_mem() : wave_sync_lds());
         if (st) { const unsigned long long now = clock64(); c_a += now - tq; tq = now; }
         // The reference's partition loop pairs the i-th element > pivot from the left with the i-th element < pivot from the right and swaps
         // them while they have not crossed. Ranks by position: the elements of (s, e] are taken 64 at a time (lane = position within the
@@ -313,16 +330,18 @@ __device__ __forceinline__ void wave_intro_select(float* d, int* idx, int n, int
         float v4[4]; unsigned long long g4[4], l4[4];                  // the first four slices stay in registers (every row of <= 257 elements)
 #pragma unroll
         for (int q = 0; q < 4; q++) {
+            g4[q] = 0ull; l4[q] = 0ull;
+            if (q > 0 && 64 * q >= L) continue;                        // (uniform: short ranges take one slice)
             const int p = s + 1 + lane + 64 * q;
             const bool in = p <= e;
-            v4[q] = in ? d[p] : piv;
+            v4[q] = in ? (p == pi ? dfront : d[p]) : piv;
             g4[q] = __ballot(in && v4[q] > piv); l4[q] = __ballot(in && v4[q] < piv);
             nG += __popcll(g4[q]); nLt += __popcll(l4[q]);
         }
         for (int base = 256; base < L; base += 256) {                  // longer rows: count the rest, four slices (reads) at a time
             float v[4];
 #pragma unroll
-            for (int q = 0; q < 4; q++) { const int p = s + 1 + lane + base + 64 * q; v[q] = p <= e ? d[p] : piv; }
+            for (int q = 0; q < 4; q++) { const int p = s + 1 + lane + base + 64 * q; v[q] = p <= e ? (p == pi ? dfront : d[p]) : piv; }
 #pragma unroll
             for (int q = 0; q < 4; q++) { nG += __popcll(__ballot(v[q] > piv)); nLt += __popcll(__ballot(v[q] < piv)); }
         }
@@ -331,6 +350,7 @@ __device__ __forceinline__ void wave_intro_select(float* d, int* idx, int n, int
             int bg = 0, bl = 0;                                        // '>' / '<' met in the slices before
 #pragma unroll
             for (int q = 0; q < 4; q++) {
+                if (q > 0 && 64 * q >= L) continue;
                 const int p = s + 1 + lane + 64 * q;
                 const int below_g = (int)__builtin_amdgcn_mbcnt_hi((unsigned)(g4[q] >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)g4[q], 0u));
                 const int below_l = (int)__builtin_amdgcn_mbcnt_hi((unsigned)(l4[q] >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)l4[q], 0u));
@@ -341,7 +361,7 @@ __device__ __forceinline__ void wave_intro_select(float* d, int* idx, int n, int
             for (int base = 256; base < L; base += 256) {
                 float v[4];
 #pragma unroll
-                for (int q = 0; q < 4; q++) { const int p = s + 1 + lane + base + 64 * q; v[q] = p <= e ? d[p] : piv; }      // (out of range: equal to the pivot, in neither set)
+                for (int q = 0; q < 4; q++) { const int p = s + 1 + lane + base + 64 * q; v[q] = p <= e ? (p == pi ? dfront : d[p]) : piv; }      // (out of range: equal to the pivot, in neither set)
 #pragma unroll
                 for (int q = 0; q < 4; q++) {
                     const int p = s + 1 + lane + base + 64 * q;

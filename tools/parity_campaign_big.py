@@ -34,8 +34,9 @@ def one(k):
 
 if __name__ == "__main__":
     npairs = int(sys.argv[1]) if len(sys.argv) > 1 else 24
+    first = int(sys.argv[2]) if len(sys.argv) > 2 else 0          # (the pair number seeds the pair: a second campaign starts where the first ended)
     bad = 0
-    for k in range(npairs):
+    for k in range(first, first + npairs):
         k, n, S, trim, ok, eo, eg, tc, tg, cev = one(k)
         print("pair %3d N=%5d S=%3d trim %.1f %s oracle %.9g gpu %.9g  cpu %.1fs gpu %.2fs cube_evals %d" % (k, n, S, trim, "SKIP" if ok is None else ("OK  " if ok else "MISMATCH"), eo, eg, tc, tg, cev), flush=True)
         bad += 1 if ok is False else 0
