@@ -269,7 +269,8 @@ __device__ __forceinline__ int wave_median_of_medians(float* d, int* idx, int s,
     }
 }
 template <bool MEM = false>
-__device__ __forceinline__ void wave_intro_select(float* d, int* idx, int n, int k, int lane, unsigned long long* st = nullptr /* diagnosis: [0] rows [1] rounds [2] median-of-medians rounds [3] cycles in them [4] cycles in the final insertion sort */) {
+__device__ __forceinline__ void wave_intro_select(float* d, int* idx, int n, int k, int lane, unsigned long long* st = nullptr /* diagnosis: [0] rows [1] rounds [2] median-of-medians rounds [3] cycles in them [4] cycles in the final insertion sort */,
+                                                  bool regsel = false /* experimental (GOICP_DBG bit 256): ranges of <= 64 elements finish in registers, one element per lane (tests/csrc/partition_check.c, reg()) */) {
     int s = 0, e = n - 1;
     int prev = e - s + 1, tries = 0; bool quick = true;
     unsigned long long n_rounds = 0, n_mom = 0, c_mom = 0, c_ins = 0, c_a = 0, c_b = 0, c_c = 0, c_d = 0, tq = 0;
@@ -297,6 +298,72 @@ __device__ __forceinline__ void wave_intro_select(float* d, int* idx, int n, int
             }
             if (st) c_ins += clock64() - t0;
             break;
+        }
+        if (regsel && quick && e - s + 1 <= 64) {
+            // ---- register regime: lane i holds d[s0 + i]; the same rounds with ballots, rank scatters and two gathers instead of LDS round trips
+            const int s0 = s, len0 = e - s + 1, kr = k - s0;
+            float w = lane < len0 ? d[s0 + lane] : 0.f;
+            int rs = 0, re = len0 - 1;
+            bool done = false;
+            const unsigned long long lo_mask = lane == 0 ? 0ull : (~0ull >> (64 - lane)), hi_mask = lane == 63 ? 0ull : (~0ull << (lane + 1));
+            for (;;) {
+                if (rs >= re) { done = true; break; }
+                n_rounds++;
+                if (re - rs <= 5) {
+                    // the reference's insertion sort of the last <= 6 elements = stable ascending order: rank by comparisons, one scatter
+                    const bool in = lane >= rs && lane <= re;
+                    int rank = 0;
+#pragma unroll
+                    for (int q = 0; q < 6; q++) {
+                        const int pq = min(rs + q, re);
+                        const float wq = __shfl(w, pq, 64);
+                        if (rs + q <= re) rank += (wq < w || (!(w < wq) && pq < lane)) ? 1 : 0;      // (wq == w in the comparison's own sense: neither is below the other)
+                    }
+                    const int dst = in ? rs + rank : lane;
+                    w = __int_as_float(__builtin_amdgcn_ds_permute(dst << 2, __float_as_int(w)));
+                    done = true; break;
+                }
+                if (tries++ == 5) { const int len = re - rs + 1; if (len * 2 > prev) quick = false; prev = len; tries = 0; }
+                if (!quick) break;                                     // no progress: the median-of-medians rounds run on the row in memory
+                const int m = (rs + re) / 2;
+                const float ds = __shfl(w, rs, 64), dm = __shfl(w, m, 64), de = __shfl(w, re, 64);
+                int pi;
+                if (ds < de) pi = dm < ds ? rs : (dm < de ? m : re);
+                else pi = dm < de ? re : (dm < ds ? m : rs);
+                const float piv = pi == rs ? ds : (pi == m ? dm : de);
+                if (pi != rs) { if (lane == pi) w = ds; if (lane == rs) w = piv; }
+                const bool in = lane > rs && lane <= re;
+                const unsigned long long g = __ballot(in && w > piv), l = __ballot(in && w < piv);
+                const int nG = __popcll(g);
+                const bool isg = (g >> lane) & 1ull, isl = (l >> lane) & 1ull;
+                const int g_below = __popcll(g & lo_mask), l_above = __popcll(l & hi_mask);
+                const bool swp = isg ? l_above > g_below : (isl ? g_below > l_above : false);
+                const int t = __popcll(__ballot(swp && isg));
+                // pair i = (i-th '>' from the left, i-th '<' from the right): both lane ids to lane i (the other lanes fill the permutation up)
+                const int dstA = isg ? g_below : nG + __popcll(~g & lo_mask);
+                const int dstB = isl ? l_above : __popcll(l) + __popcll(~l & hi_mask);
+                const int A = __builtin_amdgcn_ds_permute(dstA << 2, lane), B = __builtin_amdgcn_ds_permute(dstB << 2, lane);
+                const int P = A | (B << 8);
+                const int q = __builtin_amdgcn_ds_bpermute((isg ? g_below : l_above) << 2, P);
+                const int partner = isg ? (q >> 8) & 255 : q & 255;
+                const float nv = __int_as_float(__builtin_amdgcn_ds_bpermute((swp ? partner : lane) << 2, __float_as_int(w)));
+                if (swp) w = nv;
+                const int iA = __shfl(B, max(t - 1, 0), 64), iB = __shfl(A, min(t, 63), 64);
+                const float dend = __shfl(w, re, 64);
+                const int hi0 = t > 0 ? iA : re;
+                int lo1 = hi0; bool lo_is_greater;
+                if (t < nG && iB < hi0) { lo1 = iB; lo_is_greater = true; }
+                else lo_is_greater = t > 0 ? true : !(dend < piv);
+                const int sp = lo_is_greater ? lo1 - 1 : lo1;
+                const float vsp = __shfl(w, sp, 64);
+                if (lane == rs) w = vsp;
+                if (lane == sp) w = piv;
+                if (sp < kr) rs = sp + 1; else if (sp > kr) re = sp - 1; else { done = true; break; }
+            }
+            if (lane < len0) d[s0 + lane] = w;
+            (MEM ? wave_sync_mem() : wave_sync_lds());
+            if (done) break;
+            s = s0 + rs; e = s0 + re;                                  // (quick is false from here on: the regime is not entered again)
         }
         if (quick && tries++ == 5) { const int len = e - s + 1; if (len * 2 > prev) quick = false; prev = len; tries = 0; }
         int pi; float piv, dfront;
@@ -561,7 +628,7 @@ __device__ __forceinline__ void sweep_tile(const DevTables& T, TileShm<BLOCK>& s
         }
         __syncthreads();
         for (int j = tid >> 6; j < NT; j += BLOCK / 64)
-            wave_intro_select<JIT>(rbuf + j * Nd, reinterpret_cast<int*>(rbuf + NT * Nd) + j * Nd, Nd, T.inlierNum - 1, tid & 63, (T.dbg & 32) && T.dbg_times ? T.dbg_times + 8 : nullptr);      // (JIT: rows in HBM)
+            wave_intro_select<JIT>(rbuf + j * Nd, reinterpret_cast<int*>(rbuf + NT * Nd) + j * Nd, Nd, T.inlierNum - 1, tid & 63, (T.dbg & 32) && T.dbg_times ? T.dbg_times + 8 : nullptr, (T.dbg & 256) != 0);      // (JIT: rows in HBM)
         __syncthreads();
         if (tid < 2 * NT) {
             const int j = tid & (NT - 1);
