@@ -103,7 +103,7 @@ __global__ __launch_bounds__(256) void k_dt_columns(const int32_t* __restrict__ 
 extern "C" int goicp_dtgpu_build(int device, int S, const int32_t* occ_cells, int n_occ, const float* dist_of_d2, int n_table, goicp_dtgpu** out) {
     if (!out) return GOICP_ERR_ARG;
     *out = nullptr;
-    if (S < 1 || S > 2048 || !occ_cells || n_occ < 1 || !dist_of_d2 || n_table < 3 * (S - 1) * (S - 1) + 1) return GOICP_ERR_ARG;
+    if (S < 1 || S > GOICP_MAX_GRID || !occ_cells || n_occ < 1 || !dist_of_d2 || n_table < 3 * (S - 1) * (S - 1) + 1) return GOICP_ERR_ARG;
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || device < 0 || device >= ndev) return GOICP_ERR_NO_DEVICE;
     if (hipSetDevice(device) != hipSuccess) return GOICP_ERR_NO_DEVICE;
@@ -120,7 +120,7 @@ extern "C" int goicp_dtgpu_build(int device, int S, const int32_t* occ_cells, in
     }
     slab_ptr.push_back((int32_t)slab_rows.size());
     const int nslab = (int)slabs.size();
-    if ((size_t)nslab * 256 > 160 * 1024 - 1024) return GOICP_ERR_ARG;          // (S <= 2048 keeps this from happening below 636 seeded slabs)
+    if ((size_t)nslab * 256 > 160 * 1024 - 1024) return GOICP_ERR_ARG;          // (S <= GOICP_MAX_GRID: cannot happen below 636 seeded slabs)
 
     bool ok = true;
     goicp_dtgpu* h = new goicp_dtgpu(); h->device = device; h->S = S; h->d_dist = nullptr; h->d_nearest = nullptr;

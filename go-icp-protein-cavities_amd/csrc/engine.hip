@@ -3153,7 +3153,7 @@ extern "C" int goicp_engine_create(const goicp_engine_desc* d, goicp_engine** ou
     *out = nullptr;
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || d->device_id < 0 || d->device_id >= ndev) return GOICP_ERR_NO_DEVICE;
-    if (d->S <= 0 || (!d->dt_dist && !d->dt_dist_dev) || d->Nd <= 0 || !d->data_xyz || !d->weights || !d->maxRotDis || d->Nm < 0) return GOICP_ERR_ARG;
+    if (d->S <= 0 || d->S > GOICP_MAX_GRID || (!d->dt_dist && !d->dt_dist_dev) || d->Nd <= 0 || !d->data_xyz || !d->weights || !d->maxRotDis || d->Nm < 0) return GOICP_ERR_ARG;
     if (d->regularizationNeighbors > 0.f) return GOICP_ERR_ARG;
     if (d->Nd > (1 << 20)) return GOICP_ERR_ARG;  // up to 8192 points the cloud is register-resident; above that it is streamed (geometric error only)
     if (d->doTrim && (d->inlierNum < 1 || d->inlierNum > d->Nd)) return GOICP_ERR_ARG;

@@ -79,6 +79,7 @@ int goicp_load_dt(goicp_handle* h, int S, const double* g4, const float* dist, c
                   const int32_t* cell_ptr, const int32_t* cell_idx) {
     if (!h || S <= 0 || !g4 || !dist) return GOICP_ERR_ARG;
     DT3D& d = h->g.dt;
+    h->g.Clear();                 // an engine that adopted the device-built grid in place must be gone (its streams drained) before the blocks go back to the pool
     d.ReleaseGpu();
     const size_t n = (size_t)S * S * S;
     d.SIZE = S; d.xMin = g4[0]; d.yMin = g4[1]; d.zMin = g4[2]; d.scale = g4[3];
@@ -206,6 +207,15 @@ static std::string stem_between(const std::string& s) {   // substr(find("/")+1,
     return s.substr(a + 1, b - a - 1);
 }
 
+// "<output stem>_rescaled.txt": the reference cuts the output path at its first '.' (jly_main.cpp:155). Here the cut is the first '.'
+// of the FILE NAME, so that a dot in a directory ("./out", "run.1/") cannot map every row to one file; for the reference's own layout
+// (output/similarK.txt) the names are the same.
+static std::string rescaled_name(const std::string& o) {
+    const size_t slash = o.find_last_of('/');
+    const size_t dot = o.find('.', slash == std::string::npos ? 0 : slash + 1);
+    return o.substr(0, dot) + "_rescaled.txt";
+}
+
 static int finish(GoICP& g, double* res, double t_reg, double t_dt, const double resc[3]) {
     for (int i = 0; i < 3; i++) { for (int j = 0; j < 3; j++) res[3 * i + j] = g.optR.val[i][j]; res[9 + i] = g.optT.val[i][0]; }
     res[12] = g.optError; res[13] = g.Nd - g.optComp; res[14] = g.Nd; res[15] = t_reg; res[16] = t_dt;
@@ -252,8 +262,7 @@ int goicp_run_pair_files(const char* base_dir, const char* target_mol2, const ch
     if (g.status == GOICP_OK) {
         write_output(output_path, t_reg, g);
         rescaled_translation(g, scale, smean, tmean, resc);
-        const std::string o = output_path;
-        write_rescaled(o.substr(0, o.find(".")) + "_rescaled.txt", t_reg, g, resc);
+        write_rescaled(rescaled_name(output_path), t_reg, g, resc);
     } else if (verbose) std::cerr << "goicp: " << g.error_message << std::endl;
     return finish(g, res, t_reg, t_dt, resc);
 }

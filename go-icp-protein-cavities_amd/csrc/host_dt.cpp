@@ -226,7 +226,6 @@ void DT3D::Build(const double* _x, const double* _y, const double* _z, int num) 
         std::vector<int32_t> fill(ncell, 0);
         for (int i = 0; i < num; i++) if (cell_of[i] >= 0) { const size_t k = (size_t)cell_of[i]; cell_idx[cell_ptr[k] + fill[k]++] = i; }
     }
-    if (S > 1000) { /* beyond the range where integer and float comparisons are proven equivalent */ }
     const auto tA = std::chrono::steady_clock::now();
     propagate_all(g);
     const auto tB = std::chrono::steady_clock::now();
@@ -281,7 +280,7 @@ int DT3D::BuildGpu(const double* _x, const double* _y, const double* _z, int num
     ReleaseGpu();
     dist.clear(); nearest.clear(); cell_color.clear(); cell_ptr.clear();
     const int S = SIZE;
-    if (num <= 0 || S < 1) return GOICP_ERR_ARG;
+    if (num <= 0 || S < 1 || S > GOICP_MAX_GRID) return GOICP_ERR_ARG;
     // grid geometry: reference jly_3ddt.cpp:899-930 (same expressions as DT3D::Build above)
     xMin = xMax = _x[0]; yMin = yMax = _y[0]; zMin = zMax = _z[0];
     for (int i = 1; i < num; i++) {

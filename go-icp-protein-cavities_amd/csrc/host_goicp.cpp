@@ -168,6 +168,8 @@ void GoICP::BuildDT() {
         if (status != GOICP_OK) { error_message = status == GOICP_ERR_NO_DEVICE ? "no usable HIP device for the device DT build" : "device DT build failed"; return; }
     } else {
         dt.ReleaseGpu();
+        // the host builder compares candidates on integer squared lengths, proven equal to the reference's float compares up to S = 1000 (host_dt.cpp)
+        if (dt.SIZE < 1 || dt.SIZE > 1000) { status = GOICP_ERR_ARG; error_message = "distTransSize outside 1..1000 (host builder); dt_mode 1 accepts up to 1290"; dt.dist.clear(); dt.nearest.clear(); dt.cell_color.clear(); dt.cell_ptr.clear(); return; }
         dt.Build(x.data(), y.data(), z.data(), Nm);
     }
     assignCellColor();

@@ -10,8 +10,10 @@ longest-first by a cheap cost proxy (source atoms x target atoms):
   * schedule="lpt": static greedy longest-processing-time assignment (each row to the least-loaded rank), no communication;
   * schedule="rr": row k -> rank k mod world (kept for reference).
 """
+import itertools
 import os
 import threading
+import time
 
 import numpy as np
 
@@ -59,8 +61,13 @@ def lpt_assign(costs, world):
     return out
 
 
+_batch_seq = itertools.count()     # run_batch calls of this process; every rank makes them in the same order, so the numbers agree across ranks
+
+
 class _SharedCounter:
-    """next() hands out 0, 1, 2, ... exactly once across all ranks and threads: an atomic add on the process group's store."""
+    """next() hands out 0, 1, 2, ... exactly once across all ranks and threads: an atomic add on the process group's store.
+    The store keeps a key for the life of the process group, so every run_batch call counts on a key of its own (`key` already
+    carries the call's sequence number)."""
 
     def __init__(self, dist, key):
         from torch.distributed import distributed_c10d as c10d
@@ -71,6 +78,19 @@ class _SharedCounter:
     def next(self):
         with self.lock:                              # one outstanding request per process (the store client is not re-entrant)
             return int(self.store.add(self.key, 1)) - 1
+
+    def sum_over_ranks(self, name, value, world, timeout_s=600.0):
+        """Every rank adds `value` under `name` and waits (control path, store only -- no collective, any backend) until all `world`
+        ranks have done so; returns the total. Used to agree on a failure before anybody enters the record gather."""
+        with self.lock:
+            self.store.add(self.key + "/" + name, int(value))
+            self.store.add(self.key + "/" + name + "/arrived", 1)
+            t0 = time.time()
+            while int(self.store.add(self.key + "/" + name + "/arrived", 0)) < world:
+                if time.time() - t0 > timeout_s:
+                    raise RuntimeError("run_batch: a rank did not reach the end of the batch within %.0f s" % timeout_s)
+                time.sleep(0.002)
+            return int(self.store.add(self.key + "/" + name, 0))
 
 
 class _LocalCounter:
@@ -126,19 +146,34 @@ def protein_paths(base_dir, src, tgt):
     return chain, aligned, os.path.join(base_dir, "rot", "rot_%s_protein.mol2" % src)
 
 
-def pair_rmsd(base_dir, src, tgt, output):
+def rescaled_name(output):
+    """"<output stem>_rescaled.txt" as goicp_run_pair_files writes it: the reference cuts the output path at its first '.'
+    (jly_main.cpp:155); the cut here is the first '.' of the FILE NAME, so a dot in a directory name cannot map every row to one
+    file (same names for the reference's own layout output/similarK.txt)."""
+    d, b = os.path.split(output)
+    return os.path.join(d, b[:b.find(".")] if "." in b else b) + "_rescaled.txt"
+
+
+def pair_rmsd(base_dir, src, tgt, output, k=None):
     """RMSD of the registration just written to `output`: the source protein is transformed with the rescaled R, t of THIS run
     (Transformation::applyTransformationProtein, reference transformation.cpp:469-539) and compared with the aligned reference
-    protein (Transformation::computeRMSD, :453-464). NaN when the protein files do not exist."""
+    protein (Transformation::computeRMSD, :453-464). NaN when the protein files do not exist.
+    A source id repeats in up to ten rows of the shipped .tsv and several rows are in flight at once (threads, ranks on one file
+    system), so the transformed protein is written under a name of THIS row, measured there, and only then moved (atomically) to
+    the reference's name rot/rot_<src>_protein.mol2 -- which therefore always holds one complete file of one of those rows."""
     from . import binding
     pp = protein_paths(base_dir, src, tgt)
     if pp is None:
         return float("nan")
     chain, aligned, rot = pp
-    resc = output[:output.find(".")] + "_rescaled.txt"      # the name the pipeline writes: cut at the FIRST '.' (transformation.cpp:405)
-    if not os.path.exists(resc) or not binding.apply_transformation_protein(resc, chain, rot):
+    resc = rescaled_name(output)
+    mine = "%s.k%s.%d.%d.tmp" % (rot, "x" if k is None else str(k), os.getpid(), threading.get_ident())
+    if not os.path.exists(resc) or not binding.apply_transformation_protein(resc, chain, mine):
         return float("nan")
-    return binding.compute_rmsd(aligned, rot)
+    try:
+        return binding.compute_rmsd(aligned, mine)
+    finally:
+        os.replace(mine, rot)
 
 
 def gpu_register_fn(base_dir, device_id=0):
@@ -173,15 +208,16 @@ def run_batch(base_dir, tsv, config, out_dir, register_fn, rank=0, world=1, limi
     release the GIL). Returns (records of this rank in the order they were taken, number of rows)."""
     jobs, n_rows = list_jobs(base_dir, tsv, limit)
     costs = [j[4] for j in jobs]
+    seq = next(_batch_seq)
     have_pg = dist is not None and dist.is_initialized() and dist.get_world_size() > 1
     if schedule is None:
         schedule = "dynamic" if (have_pg or world == 1) else "lpt"
     order = lpt_order(costs)
-    counter = None
+    counter = shared = None
     if schedule == "dynamic":
         if have_pg:
             try:
-                counter = _SharedCounter(dist, counter_key)
+                counter = shared = _SharedCounter(dist, "%s_%d" % (counter_key, seq))
             except Exception:
                 schedule = "lpt"                    # no store access: static longest-first partition instead
         elif world == 1:
@@ -200,7 +236,7 @@ def run_batch(base_dir, tsv, config, out_dir, register_fn, rank=0, world=1, limi
         k, tf, sf, nd, _, src, tgt = job
         output = os.path.join(out_dir, "similar%d.txt" % k)
         res = register_fn(tf, sf, nd, config, output, k)
-        val = pair_rmsd(base_dir, src, tgt, output) if (rmsd and int(res.get("status", 0)) == 0) else float("nan")
+        val = pair_rmsd(base_dir, src, tgt, output, k) if (rmsd and int(res.get("status", 0)) == 0) else float("nan")
         return pack_record(k, res, rmsd=val, rank=rank)
 
     recs = []; lock = threading.Lock()
@@ -237,7 +273,20 @@ def run_batch(base_dir, tsv, config, out_dir, register_fn, rank=0, world=1, limi
             t.join()
     else:
         worker()
+    # A rank that failed must not leave the others waiting in the record gather that follows: under a process group all ranks agree
+    # on the failure count first (store only), and every rank raises.
+    failed_ranks = 0
+    if have_pg:
+        if shared is None:
+            try:
+                shared = _SharedCounter(dist, "%s_%d" % (counter_key, seq))
+            except Exception:
+                shared = None
+        if shared is not None:
+            failed_ranks = shared.sum_over_ranks("failed", 1 if errors else 0, dist.get_world_size())
     if errors:
         raise errors[0]
+    if failed_ranks:
+        raise RuntimeError("run_batch: %d other rank(s) failed; no records gathered" % failed_ranks)
     recs.sort(key=lambda r: r[0])
     return recs, n_rows

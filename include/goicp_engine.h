@@ -42,6 +42,7 @@ extern "C" {
 
 #define GOICP_MAXROTLEVEL 20       /* jly_goicp.h:95 */
 #define GOICP_FPFH_BINS   41       /* jly_main.cpp:301 */
+#define GOICP_MAX_GRID    1290     /* largest grid side: linear cell indices are int32 throughout (1290^3 < 2^31 <= 1291^3); larger S -> GOICP_ERR_ARG */
 
 typedef struct goicp_engine goicp_engine;
 

@@ -85,11 +85,50 @@ def test_pair_rmsd_of_the_planted_pose_is_zero(small_batch, tmp_path):
     jobs, _ = driver.list_jobs(d, tsv)
     k, tf, sf, nd, cost, src, tgt = jobs[5]
     R, t = truth[k - 1]
-    out = os.path.join(str(tmp_path).replace(".", "_"), "similar%d.txt" % k); os.makedirs(os.path.dirname(out), exist_ok=True)
-    with open(out[:out.find(".")] + "_rescaled.txt", "w") as f:
-        f.write("Time: 0\nRotation Matrix:\n" + "\n".join("   %.9g   %.9g   %.9g" % tuple(r) for r in R) + "\nTranslation Vector:\n" + "\n".join("   %.9g" % v for v in t) + "\nError: 0\n")
-    assert driver.pair_rmsd(d, src, tgt, out) < 2e-3
+    out = os.path.join(str(tmp_path), "run.1", "similar%d.txt" % k); os.makedirs(os.path.dirname(out), exist_ok=True)   # a dot in a DIRECTORY name
+    assert driver.rescaled_name(out) == os.path.join(str(tmp_path), "run.1", "similar%d_rescaled.txt" % k)
+    assert driver.rescaled_name("output/similar7.txt") == "output/similar7_rescaled.txt"           # the reference's own layout: same name as its rule gives
+    _write_rescaled(driver.rescaled_name(out), R, t)
+    assert driver.pair_rmsd(d, src, tgt, out, k) < 2e-3
     assert np.isnan(driver.pair_rmsd(d, "nosuch", tgt, out))
+    assert os.path.exists(os.path.join(d, "rot", "rot_%s_protein.mol2" % src))                    # the reference's name holds the finished file
+    assert not [f for f in os.listdir(os.path.join(d, "rot")) if f.endswith(".tmp")]
+
+
+def _write_rescaled(path, R, t):
+    with open(path, "w") as f:
+        f.write("Time: 0\nRotation Matrix:\n" + "\n".join("   %.9g   %.9g   %.9g" % tuple(r) for r in R) + "\nTranslation Vector:\n" + "\n".join("   %.9g" % v for v in t) + "\nError: 0\n")
+
+
+def test_rows_that_share_a_source_do_not_share_the_transformed_protein(small_batch, tmp_path):
+    """A source id repeats in up to ten rows of the shipped .tsv (3lzs_1 x10) and longest-first ordering runs them side by side: every
+    row must measure ITS OWN transformed protein. Eight threads evaluate the same source at once, half with the planted pose (RMSD ~ 0)
+    and half with a pose 5 Angstrom off; each must get its own answer."""
+    import threading
+    d, tsv, cfgp, truth = small_batch
+    jobs, _ = driver.list_jobs(d, tsv)
+    k, tf, sf, nd, cost, src, tgt = jobs[6]
+    R, t = truth[k - 1]
+    outs = []
+    for i in range(8):
+        o = os.path.join(str(tmp_path), "similar%d.txt" % (100 + i)); outs.append(o)
+        _write_rescaled(driver.rescaled_name(o), R, t + (5.0 if i % 2 else 0.0))
+    got = [None] * 8
+
+    def run(i):
+        for _ in range(6):
+            got[i] = driver.pair_rmsd(d, src, tgt, outs[i], 100 + i)
+            assert (got[i] > 4.0) if i % 2 else (got[i] < 2e-3), (i, got[i])
+    errs = []
+
+    def guarded(i):
+        try:
+            run(i)
+        except BaseException as e:
+            errs.append(e)
+    ts = [threading.Thread(target=guarded, args=(i,)) for i in range(8)]
+    [x.start() for x in ts]; [x.join() for x in ts]
+    assert not errs, errs
 
 
 def _slow_fake_register(tf, sf, nd, config, output, k):
@@ -107,6 +146,24 @@ def _worker(rank, world, port, tmp, base, tsv, schedule):
     if rank == 0:
         np.save(os.path.join(tmp, "gathered_%s.npy" % schedule), allr)
     np.save(os.path.join(tmp, "local_%s_%d.npy" % (schedule, rank)), np.array(recs).reshape(-1, driver.REC))
+    # a SECOND batch in the same process group, same counter key (bench.py: warm-up pass, then the timed pass): it must hand out every row again
+    recs2, _ = driver.run_batch(base, tsv, "unused", os.path.join(tmp, "out%d" % rank), _slow_fake_register, rank=rank, world=world, threads=2,
+                                schedule=schedule, dist=dist, counter_key="next_" + schedule)
+    allr2 = driver.gather_records(recs2, n_total, dist=dist)
+    if rank == 0:
+        np.save(os.path.join(tmp, "gathered2_%s.npy" % schedule), allr2)
+    # a batch in which ONE rank's registration fails: every rank must raise (nobody left waiting in the gather)
+    def failing(tf, sf, nd, config, output, k):
+        if rank == 1:
+            raise RuntimeError("planted failure")
+        return _slow_fake_register(tf, sf, nd, config, output, k)
+    try:
+        driver.run_batch(base, tsv, "unused", os.path.join(tmp, "out%d" % rank), failing, rank=rank, world=world, threads=2, schedule=schedule, dist=dist,
+                         counter_key="next_" + schedule)
+        raised = ""
+    except RuntimeError as e:
+        raised = str(e)
+    open(os.path.join(tmp, "raised_%s_%d.txt" % (schedule, rank)), "w").write(raised)
     dist.barrier()
     dist.destroy_process_group()
 
@@ -121,6 +178,9 @@ def test_two_rank_gloo_batch(tmp_path, small_batch, schedule):
     allr = np.load(os.path.join(str(tmp_path), "gathered_%s.npy" % schedule))
     assert allr.shape == (14, driver.REC)
     assert list(allr[:, 0]) == [float(k) for k in range(1, 15)]
+    assert np.array_equal(np.load(os.path.join(str(tmp_path), "gathered2_%s.npy" % schedule))[:, :21], allr[:, :21], equal_nan=True)    # second batch of the group: all rows again
+    r0 = open(os.path.join(str(tmp_path), "raised_%s_0.txt" % schedule)).read(); r1 = open(os.path.join(str(tmp_path), "raised_%s_1.txt" % schedule)).read()
+    assert "planted failure" in r1 and "rank(s) failed" in r0
     assert allr[0, 15] == 238 and allr[1, 15] == 247            # Nd read from line 6 of the source mol2
     assert allr[1, 13] == 20.0 and np.array_equal(allr[1, 10:13], [2, 3, 4])
     l0 = np.load(os.path.join(str(tmp_path), "local_%s_0.npy" % schedule)); l1 = np.load(os.path.join(str(tmp_path), "local_%s_1.npy" % schedule))

@@ -72,6 +72,17 @@ def test_unsupported_configurations_fail_at_create():
                          data_color=np.zeros(nb, np.int32), **big)
     e = goicp_amd.Engine(**big)                         # the same cloud without penalties is accepted
     e.close()
+    # grid sides above GOICP_MAX_GRID = 1290 overflow the int32 linear cell index: refused before anything is read or allocated
+    with pytest.raises(goicp_amd.EngineError):
+        goicp_amd.Engine(**dict(base, S=1291))
+    g = goicp_amd.GoICP(goicp_amd.cfg_vector(distTransSize=1291), dt_mode=1); g.set_clouds(P["t"], P["s"])
+    with pytest.raises(goicp_amd.EngineError):
+        g.build_dt()
+    g.close()
+    g = goicp_amd.GoICP(goicp_amd.cfg_vector(distTransSize=1001)); g.set_clouds(P["t"], P["s"])      # host builder: proven up to 1000
+    with pytest.raises(goicp_amd.EngineError):
+        g.build_dt()
+    g.close()
 
 
 def test_more_than_16_colour_codes_is_rejected():

@@ -218,6 +218,22 @@ def test_register_demo_rand_known_answers_gpu():
         g.close()
 
 
+@pytest.mark.parametrize("name", ["bunny_S100", "bunny_S300"])
+def test_register_bunny_known_answers_on_the_default_grid(name):
+    """BASELINE configs[0]: the upstream bunny demo (35 947 model points, first 1000 data points) on the DEFAULT path -- host-built
+    reference-order grid, parity_mode 1. Nd = 1000 <= 1024, so error, trace and pop count are the compiled reference's bit for bit
+    (bunny_S300 is the reference's own shipped demo/output.txt configuration)."""
+    G = load_register()[name]
+    B = np.load(os.path.join(GOLDEN, "data", "demo", "bunny.npz"))
+    g = goicp_amd.GoICP(cfg_vector(**G["cfg"])[0]); g.set_clouds(B["model"], B["data"][:1000]); g.build_dt()
+    out = g.register()
+    assert float(out["error"]) == G["error"], (out["error"], G["error"])
+    assert np.abs(out["R"] - np.array(G["R"])).max() < 1e-5 and np.abs(out["t"] - np.array(G["t"])).max() < 1e-5
+    assert [(a, float("%g" % b)) for a, b in out["trace"]] == [tuple(x) for x in G["trace"]]
+    assert out["stats"]["trans_pops"] == G["trans_pops"]
+    g.close()
+
+
 def test_speculative_batching_does_not_change_the_result():
     G = load_register()["pair1_fpfh33"]; P = load_clouds("pair1")
     outs = []

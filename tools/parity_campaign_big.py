@@ -1,7 +1,11 @@
-"""Randomised parity campaign above 1024 points (run on the GPU box): GoICP::Register() with parity_mode 2 (reference-order sums on rows in HBM;
-register-resident clouds up to 5120 points, streamed beyond) vs the plain-C oracle on seeded synthetic pairs -- geometric error, trimmed and
-untrimmed, 50^3 / 100^3 grids. One line per pair and a summary; exit status 1 on any mismatch.
-Test infrastructure (uses oracle/): python tools/parity_campaign_big.py [n_pairs]"""
+"""Randomised parity campaign above 1024 points (run on the GPU box): GoICP::Register() vs the plain-C oracle on seeded synthetic pairs --
+geometric error, trimmed and untrimmed, 50^3 / 100^3 grids.
+  parity_mode 2: reference-order sums on rows in HBM -> compared bit for bit (error, trace; R, t < 1e-9);
+  parity_mode 1 (the product default, the path bench.py times): fp64 sums above 1024 points -> R, t within 1e-5, error within
+                max(1e-5, n 2^-24) relative, and the same number of translation-queue pops (a different pop count means a decision flipped
+                on a near-tie, even if the search then lands on the same node).
+One line per pair and a summary; exit status 1 on any mismatch.
+Test infrastructure (uses oracle/): python tools/parity_campaign_big.py [n_pairs] [first_pair] [parity_mode]"""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -10,8 +14,11 @@ import goicp_amd
 from oracle.refbind import cfg_vector, error_trace
 from helpers import synth_pair, oracle_for
 
+BUDGET = 120000          # cube evaluations the single-threaded oracle is asked to repeat
 
-def one(k):
+
+def case(k):
+    """The seeded pair number k: (points, trimFraction, grid size, config overrides, clouds)."""
     rng = np.random.default_rng(77000 + k)
     n = int(rng.choice([1100, 1500, 2048, 2049, 3000, 4096, 5000, 5120, 5121, 7000, 9000]))
     trim = float(rng.choice([0.0, 0.1, 0.2]))
@@ -19,26 +26,45 @@ def one(k):
     outl = 0.0 if trim == 0.0 else float(rng.choice([0.05, 0.1]))         # (an untrimmed search on outliers runs for hours, in the reference too)
     over = dict(distTransSize=S, trimFraction=trim, regularization=0.0, ponderation=0, MSEThresh=0.002)
     P = synth_pair(n, seed=88000 + k, noise=0.005, outlier_frac=outl, theta_range=(0.3, np.pi))
+    return n, trim, S, over, P
+
+
+def one(k, pm):
+    n, trim, S, over, P = case(k)
     v, _ = cfg_vector(**over)
     t0 = time.time()
-    g = goicp_amd.GoICP(goicp_amd.cfg_vector(**over), parity_mode=2); g.set_clouds(P["t"], P["s"]); g.build_dt()
+    g = goicp_amd.GoICP(goicp_amd.cfg_vector(**over), parity_mode=pm); g.set_clouds(P["t"], P["s"]); g.build_dt()
     rg = g.register(); g.close(); t_gpu = time.time() - t0
-    if rg["stats"]["cube_evals"] > 120000:
-        return k, n, S, trim, None, float("nan"), float(rg["error"]), 0.0, t_gpu, rg["stats"]["cube_evals"]
+    rec = dict(k=k, n=n, S=S, trim=trim, ok=None, eo=float("nan"), eg=float(rg["error"]), tc=0.0, tg=t_gpu, cev=rg["stats"]["cube_evals"],
+               pg=rg["stats"]["trans_pops"], po=-1, dR=float("nan"), dt=float("nan"))
+    if rg["stats"]["cube_evals"] > BUDGET:
+        return rec
     t0 = time.time()
-    o = oracle_for(P, v); ro = o.register(); t_cpu = time.time() - t0
-    ok = (float(rg["error"]) == float(ro["error"]) and np.abs(rg["R"] - ro["R"]).max() < 1e-9 and np.abs(rg["t"] - ro["t"]).max() < 1e-9
-          and [(a, float("%g" % b)) for a, b in rg["trace"]] == error_trace(ro["log"]))
-    return k, n, S, trim, ok, float(ro["error"]), float(rg["error"]), t_cpu, t_gpu, rg["stats"]["cube_evals"]
+    o = oracle_for(P, v); o.counters(); ro = o.register(); rec["tc"] = time.time() - t0
+    rec["po"] = o.counters()[0]; rec["eo"] = float(ro["error"])
+    rec["dR"] = float(np.abs(rg["R"] - ro["R"]).max()); rec["dt"] = float(np.abs(rg["t"] - ro["t"]).max())
+    if pm == 2:
+        rec["ok"] = bool(float(rg["error"]) == float(ro["error"]) and rec["dR"] < 1e-9 and rec["dt"] < 1e-9 and rec["pg"] == rec["po"]
+                         and [(a, float("%g" % b)) for a, b in rg["trace"]] == error_trace(ro["log"]))
+    else:
+        tol = max(1e-5, n * 2.0 ** -24)
+        rec["ok"] = bool(abs(rec["eg"] - rec["eo"]) <= tol * max(rec["eo"], 1e-30) + 1e-12 and rec["dR"] < 1e-5 and rec["dt"] < 1e-5
+                         and rec["pg"] == rec["po"] and [a for a, _ in rg["trace"]] == [a for a, _ in error_trace(ro["log"])])
+    return rec
 
 
 if __name__ == "__main__":
     npairs = int(sys.argv[1]) if len(sys.argv) > 1 else 24
     first = int(sys.argv[2]) if len(sys.argv) > 2 else 0          # (the pair number seeds the pair: a second campaign starts where the first ended)
-    bad = 0
+    pm = int(sys.argv[3]) if len(sys.argv) > 3 else 2
+    bad = cmp = 0
+    print("parity_mode %d, pairs %d..%d" % (pm, first, first + npairs - 1))
     for k in range(first, first + npairs):
-        k, n, S, trim, ok, eo, eg, tc, tg, cev = one(k)
-        print("pair %3d N=%5d S=%3d trim %.1f %s oracle %.9g gpu %.9g  cpu %.1fs gpu %.2fs cube_evals %d" % (k, n, S, trim, "SKIP" if ok is None else ("OK  " if ok else "MISMATCH"), eo, eg, tc, tg, cev), flush=True)
-        bad += 1 if ok is False else 0
-    print("pairs %d mismatches %d" % (npairs, bad))
+        r = one(k, pm)
+        print("pair %3d N=%5d S=%3d trim %.1f %s oracle %.9g gpu %.9g  dR %.2e dt %.2e pops %d/%d  cpu %.1fs gpu %.2fs cube_evals %d" % (
+            r["k"], r["n"], r["S"], r["trim"], "SKIP" if r["ok"] is None else ("OK  " if r["ok"] else "MISMATCH"), r["eo"], r["eg"], r["dR"], r["dt"],
+            r["pg"], r["po"], r["tc"], r["tg"], r["cev"]), flush=True)
+        bad += 1 if r["ok"] is False else 0
+        cmp += 0 if r["ok"] is None else 1
+    print("parity_mode %d pairs %d compared %d mismatches %d" % (pm, npairs, cmp, bad))
     sys.exit(1 if bad else 0)
