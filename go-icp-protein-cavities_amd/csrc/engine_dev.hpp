@@ -1,0 +1,1807 @@
+// engine_dev.hpp -- device side shared by the kernel translation units of libgoicp_hip.so (k_bnb.hip, k_fr.hip, k_eval.hip, engine.hip):
+// tables, the DT lookup, the tile sweeps (sweep_tile / sweep_stream), the reference-order selection, the corner-lattice terms and the
+// replayed priority queue. Everything here is __device__ inline code or plain structs; the kernels and their launchers live in the .hip files.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <math.h>
+#include <string>
+#include <vector>
+#include <map>
+#include <algorithm>
+#include <mutex>
+
+#include "goicp_engine.h"
+#include "pool.hpp"
+#include "kabsch.hpp"
+
+#define TC 8            // cubes per workgroup tile (the 8 children of one queue pop)
+#define CAND_CAP 128     // threshold-bin members refined inside one wave; larger bins take the generic byte passes
+#define NLMAX 64        // lattice points per tile: 27 (shared child corners) or 8*TC (free cubes)
+#define SQRT3_D 1.732050808   // jly_goicp.h:45
+// Diagnosis bits of GOICP_DBG (cycle stamps: 32, 64; ablations that make results WRONG: 1 no selection, 2 gathers forced into a 4 KB window,
+// 128 no fused pop) exist only in a `make PROBES=1` build; the shipped library compiles them out.
+#ifdef GOICP_PROBES
+#define DBG_ON(T, bit) ((((T).dbg) & (bit)) != 0)
+#else
+#define DBG_ON(T, bit) false
+#endif
+
+struct DevTables {
+    int S;
+    double xMin, yMin, zMin, scale;
+    const float* dist;
+    // 2-byte coded copy of the grid (see k_build_codes): code = squared cell distance d2 when dist == lut[d2] bit for bit and d2 < 65535,
+    // else 0xFFFF (the value is then read from `dist`). Twice the cells per cache line of the gather stream; null = not built.
+    const uint16_t* code; const float* lut;
+    const uint16_t* cmask;
+    const int* occ;          // [S^3] compact id of the nearest occupied cell, -1 if none
+    const int* occ_ptr;      // [nOcc+1]
+    const int* occ_pts;      // model ids
+    const float* mfpfh;      // [Nm*41]
+    const float* dfpfh;      // [Nd*41]
+    const float* fpE;        // [Nd*nOcc] min over the model points of occupied cell o of the L1 distance to data point i's descriptor
+    int nOcc;
+    const float* dxyz;       // [Nd*3]
+    const uint8_t* dcls;     // [Nd] colour class of each data point
+    const float* weights;    // [Nd]
+    const float* maxRotDis;  // [20*Nd]
+    int Nd, Nm, inlierNum, doTrim, norm, b0, b1;
+    float reg, regFPFH;
+    int use_compat, use_fpfh, exact;
+    int exact_big;           // parity_mode 2, 1025..5120 points, geometric error: reference-order sums / intro_select on residual rows in HBM (xrows)
+    int exact_stream;        // parity_mode 2 on a streamed cloud: the same on [2 * TC][NdP] rows per resident workgroup (srows)
+    float* xrows; int xslots; // [xslots][2 * TC * NdP] floats: addend / residual rows + selection scratch of one workgroup each
+    float4* srot;            // streaming path (Nd > 8192): per-workgroup rotated cloud [NdP]
+    float* srows;            // streaming path, trimmed runs: per-workgroup residual rows [TC][NdP]
+    int NdP;                 // row pitch of the two above
+    int dbg;                 // GOICP_DBG ablation bits (diagnosis only; results are wrong when set)
+    unsigned long long* dbg_times;   // [8] per-phase cycle sums of job 0, lane 0 (GOICP_DBG & 32)
+};
+
+struct __attribute__((aligned(8))) HeapNode { float x, y, z, w, ub, lb; };
+
+// ---------------------------------------------------------------------------------------------
+// device helpers
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ int cell_of(float v, double mn, double scale) {
+    // ROUND((x - xMin) * scale), reference jly_3ddt.cpp:30,1142-1144: double math, truncation toward zero
+    return (int)(((double)v - mn) * scale + 0.5);
+}
+
+// DT3D::Distance (reference jly_3ddt.cpp:1139-1191) split in two so that a lane can put many gathers in flight
+// before it consumes the first one: dt_index() does the (double) cell arithmetic and yields the clamped cell plus
+// the out-of-grid extension length (0 inside the grid); dt_finish() applies the extension to the fetched value.
+__device__ __forceinline__ unsigned dt_index(const DevTables& T, float X, float Y, float Z, float& ext) {
+    const int S = T.S;
+    int x = cell_of(X, T.xMin, T.scale), y = cell_of(Y, T.yMin, T.scale), z = cell_of(Z, T.zMin, T.scale);
+    const int ax = x < 0 ? x : (x >= S ? x - S + 1 : 0);
+    const int ay = y < 0 ? y : (y >= S ? y - S + 1 : 0);
+    const int az = z < 0 ? z : (z >= S ? z - S + 1 : 0);
+    x = min(max(x, 0), S - 1); y = min(max(y, 0), S - 1); z = min(max(z, 0), S - 1);
+    ext = 0.f;
+    if ((ax | ay | az) != 0) { const float a = (float)ax, b = (float)ay, c = (float)az; ext = sqrtf(a * a + b * b + c * c); }
+    return (unsigned)((z * S + y) * S + x);
+}
+// one axis of dt_index(): unclamped cell coordinate; clamping is a single v_med3_i32 and the out-of-grid offset is only
+// formed on the (rare) lanes that need it
+__device__ __forceinline__ int clamp_cell(int x, int S) {
+    int r;
+    asm("v_med3_i32 %0, %1, 0, %2" : "=v"(r) : "v"(x), "s"(S - 1));
+    return r;
+}
+__device__ __forceinline__ int grid_off(int x, int S) { return x < 0 ? x : (x >= S ? x - S + 1 : 0); }
+// extension length from UNCLAMPED cell coordinates (0 when the cell is inside the grid)
+__device__ __forceinline__ float dt_ext_raw(int x, int y, int z, int S) {
+    float ext = 0.f;
+    if (((unsigned)x >= (unsigned)S) | ((unsigned)y >= (unsigned)S) | ((unsigned)z >= (unsigned)S)) {
+        const float a = (float)grid_off(x, S), b = (float)grid_off(y, S), c = (float)grid_off(z, S);
+        ext = sqrtf(a * a + b * b + c * c);
+    }
+    return ext;
+}
+__device__ __forceinline__ float dt_finish(const DevTables& T, float v, float ext) {
+    if (ext > 0.f) v = (float)((double)ext / T.scale + (double)v);      // float sqrt, double divide and add, rounded to float
+    return v;
+}
+__device__ __forceinline__ float dt_lookup(const DevTables& T, float X, float Y, float Z) {
+    float ext;
+    const unsigned idx = dt_index(T, X, Y, Z, ext);
+    return dt_finish(T, T.dist[idx], ext);
+}
+
+#define LUT_LDS 8192      // leading LUT entries a sweep kernel keeps in LDS (squared cell distances below 8192: within 90 cells of the model)
+// value of cell idx through the coded grid: code -> LUT (LDS copy for small codes, global beyond), escape -> the float grid
+__device__ __forceinline__ float dt_decode(const DevTables& T, unsigned idx, unsigned c, const float* lut_lds) {
+    if (c < (unsigned)LUT_LDS && lut_lds) {
+        const __attribute__((address_space(3))) float* q = (const __attribute__((address_space(3))) float*)lut_lds;
+        return q[c];
+    }
+    return c != 0xFFFFu ? T.lut[c] : T.dist[idx];
+}
+
+__device__ __forceinline__ size_t clamped_cell(const DevTables& T, float X, float Y, float Z) {
+    // checkCompatibility / computeFPFHDifference prologue (reference jly_goicp.cpp:974-985, 1642-1651)
+    const int S = T.S;
+    int x = cell_of(X, T.xMin, T.scale), y = cell_of(Y, T.yMin, T.scale), z = cell_of(Z, T.zMin, T.scale);
+    x = x < 0 ? 0 : (x >= S ? S - 1 : x);
+    y = y < 0 ? 0 : (y >= S ? S - 1 : y);
+    z = z < 0 ? 0 : (z >= S ? S - 1 : z);
+    return ((size_t)z * S + y) * S + x;
+}
+
+// min over the model points of the nearest occupied cell of the L1 distance between c-FPFH rows
+// (computeFPFHDifference(false,...), reference jly_goicp.cpp:1642-1681). The value depends only on (data point,
+// occupied cell), not on the pose, so it is tabulated once per engine (k_fpfh_table) and the hot path does one gather.
+__device__ __forceinline__ float fpfh_min(const DevTables& T, int i, float X, float Y, float Z) {
+    const int o = T.occ[clamped_cell(T, X, Y, Z)];
+    return o < 0 ? 1000000000.f : T.fpE[(size_t)i * T.nOcc + o];
+}
+
+
+__device__ __forceinline__ double cube_sum(double v) {       // over the 8 lanes of a wave that hold the same (lane & 7)
+    v += __shfl_xor(v, 8, 64); v += __shfl_xor(v, 16, 64); v += __shfl_xor(v, 32, 64);
+    return v;
+}
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+    return v;
+}
+
+// Histogram increment for a whole wave. Residual sets are often dominated by one value (every residual that the
+// rotation-uncertainty radius clamps to 0 is bit-identical), and 64 lanes adding to one LDS word serialise; so the
+// lanes that share the first taker's key are counted with one ballot and added once, the others add individually.
+__device__ __forceinline__ void hist_add(unsigned* row, unsigned key, bool take, int ln) {
+    const unsigned long long tk = __ballot(take);
+    if (!tk) return;
+    const int leader = __ffsll((long long)tk) - 1;
+    const unsigned k0 = (unsigned)__shfl((int)key, leader, 64);
+    const unsigned long long same = __ballot(take && key == k0);
+    if (ln == leader) atomicAdd(&row[k0], (unsigned)__popcll(same));
+    if (take && key != k0) atomicAdd(&row[key], 1u);
+}
+
+// ---------------------------------------------------------------------------------------------
+// intro_select of the reference (jly_sorting.hpp:34-313) with its exact swap sequence, run by one wave on a residual row in
+// LDS. Parity mode uses it for trimmed runs of small clouds: the permutation it leaves behind fixes the order of the
+// float sums that follow (jly_goicp.cpp:389-415), so the bounds come out bit-identical to the reference's.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ int sel_pivot_ends(const float* d, int s, int e) {
+    const int m = (s + e) / 2;
+    if (d[s] < d[e]) return d[m] < d[s] ? s : (d[m] < d[e] ? m : e);
+    return d[m] < d[e] ? e : (d[m] < d[s] ? m : s);
+}
+__device__ inline int sel_med3(const float* d, int s) {
+    if (d[s] < d[s + 2]) return d[s + 1] < d[s] ? s : (d[s + 1] < d[s + 2] ? s + 1 : s + 2);
+    return d[1] < d[2] ? s + 2 : (d[1] < d[0] ? s + 1 : s);            // absolute indices 0..2, as in jly_sorting.hpp:74-80
+}
+__device__ inline int sel_med5(float* d, int s) {
+    float* q = d + s; float t;
+    if (q[0] > q[1]) { t = q[0]; q[0] = q[1]; q[1] = t; }
+    if (q[2] > q[3]) { t = q[2]; q[2] = q[3]; q[3] = t; }
+    if (q[0] < q[2]) { t = q[4]; q[4] = q[0]; if (t < q[1]) q[0] = t; else { q[0] = q[1]; q[1] = t; } }
+    else { t = q[4]; q[4] = q[2]; if (t < q[3]) q[2] = t; else { q[2] = q[3]; q[3] = t; } }
+    if (q[0] < q[2]) return q[1] < q[2] ? s + 1 : s + 2;
+    return q[0] < q[3] ? s : s + 3;
+}
+// Wave-parallel form of the same selection: one wave per residual row. The reference's partition loop pairs the i-th element
+// > pivot from the left with the i-th element < pivot from the right and swaps them while they have not crossed; that final
+// arrangement (and the pivot's resting place) is a pure function of the row, so it is computed with ballots / prefix counts
+// instead of a cell-by-cell scan, and the result is bit-identical to the sequential routine (tests/csrc/partition_check.c). `idx` is scratch of n ints.
+__device__ __forceinline__ void wave_sync_lds() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+// the same hand-off between the lanes of a wave when the data may live in HBM (rows of parity_mode 2): workgroup scope makes the compiler wait for the
+// outstanding vector-memory operations as well (a CU's waves share its L1, so nothing has to be written back or invalidated)
+__device__ __forceinline__ void wave_sync_mem() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+}
+// sel_median_of_medians for a whole wave. The group medians of a pass are independent of each other (a group is only modified by its own
+// sel_med5 and, later, by front swaps of groups 5 times further on), so every lane takes groups of its own: sel_med5 in registers with the
+// reference's in-place moves written back. The front swaps "d[s+i] <-> d[median of group i]" keep the sequential result when they are applied
+// level by level: swap i can only meet swap floor(i/5) (whose group holds the slot s+i), so swaps [0,1), [1,5), [5,25), [25,125), ... are
+// independent inside a level. The last (short) group and the final choice stay on lane 0 (sel_med3 reads absolute indices, jly_sorting.hpp:74-80).
+// idx: scratch of at least (e - s + 1) / 5 + 1 ints. Returns the pivot's index (uniform).
+template <bool MEM>
+__device__ __forceinline__ int wave_median_of_medians(float* d, int* idx, int s, int e, int lane) {
+    for (;;) {
+        const int len = e - s + 1, groups = len / 5 + (len % 5 != 0);
+        const int nfull = groups - 1;                                  // groups that are certainly complete (the loop of the reference)
+        for (int it = lane; it < nfull; it += 64) {
+            float* q = d + s + 5 * it;
+            float q0 = q[0], q1 = q[1], q2 = q[2], q3 = q[3], q4 = q[4], t;
+            if (q0 > q1) { t = q0; q0 = q1; q1 = t; }
+            if (q2 > q3) { t = q2; q2 = q3; q3 = t; }
+            int m;
+            if (q0 < q2) { t = q4; q4 = q0; if (t < q1) q0 = t; else { q0 = q1; q1 = t; } }
+            else { t = q4; q4 = q2; if (t < q3) q2 = t; else { q2 = q3; q3 = t; } }
+            if (q0 < q2) m = q1 < q2 ? 1 : 2; else m = q0 < q3 ? 0 : 3;
+            q[0] = q0; q[1] = q1; q[2] = q2; q[3] = q3; q[4] = q4;
+            idx[it] = s + 5 * it + m;
+        }
+        (MEM ? wave_sync_mem() : wave_sync_lds());
+        for (int lo = 0, hi = 1; lo < nfull; lo = hi, hi *= 5) {
+            for (int i = lo + lane; i < min(hi, nfull); i += 64) { const int mi = idx[i]; const float t = d[s + i]; d[s + i] = d[mi]; d[mi] = t; }
+            (MEM ? wave_sync_mem() : wave_sync_lds());
+        }
+        int ret = 0;
+        if (lane == 0) {
+            const int g = s + 5 * nfull, rest = e - g + 1;
+            const int mi = (rest == 3 || rest == 4) ? sel_med3(d, g) : (rest == 5 ? sel_med5(d, g) : g);
+            const float t = d[s + nfull]; d[s + nfull] = d[mi]; d[mi] = t;
+            if (groups <= 5) ret = (groups == 3 || groups == 4) ? sel_med3(d, s) : (groups == 5 ? sel_med5(d, s) : s);
+        }
+        (MEM ? wave_sync_mem() : wave_sync_lds());
+        if (groups > 5) { e = s + groups - 1; continue; }
+        return __shfl(ret, 0, 64);
+    }
+}
+template <bool MEM = false>
+__device__ __forceinline__ void wave_intro_select(float* d, int* idx, int n, int k, int lane, unsigned long long* st = nullptr /* diagnosis: [0] rows [1] rounds [2] median-of-medians rounds [3] cycles in them [4] cycles in the final insertion sort */,
+                                                  bool regsel = false /* experimental (GOICP_DBG bit 256): ranges of <= 64 elements finish in registers, one element per lane (tests/csrc/partition_check.c, reg()) */) {
+    int s = 0, e = n - 1;
+    int prev = e - s + 1, tries = 0; bool quick = true;
+    unsigned long long n_rounds = 0, n_mom = 0, c_mom = 0, c_ins = 0, c_a = 0, c_b = 0, c_c = 0, c_d = 0, tq = 0;
+    for (;;) {
+        if (s >= e) break;
+        n_rounds++;
+        if (e - s <= 5) {
+            const unsigned long long t0 = st ? clock64() : 0ull;
+            // (the reference's insertion sort of the last <= 6 elements: the sorted arrangement is a function of the values alone, so the
+            // elements are fetched together, sorted in registers and written back by lane 0 instead of ~15 dependent round trips)
+            {
+                const int cnt = e - s + 1;
+                float w[6];
+#pragma unroll
+                for (int q = 0; q < 6; q++) w[q] = q < cnt ? d[s + q] : __builtin_inff();
+#pragma unroll
+                for (int i = 1; i < 6; i++) {
+#pragma unroll
+                    for (int j = i; j > 0; j--) { const float a = w[j - 1], b = w[j]; const bool sw = a > b; w[j - 1] = sw ? b : a; w[j] = sw ? a : b; }
+                }
+                if (lane == 0) {
+#pragma unroll
+                    for (int q = 0; q < 6; q++) if (q < cnt) d[s + q] = w[q];
+                }
+            }
+            if (st) c_ins += clock64() - t0;
+            break;
+        }
+        if (regsel && quick && e - s + 1 <= 64) {
+            // ---- register regime: lane i holds d[s0 + i]; the same rounds with ballots, rank scatters and two gathers instead of LDS round trips
+            const int s0 = s, len0 = e - s + 1, kr = k - s0;
+            float w = lane < len0 ? d[s0 + lane] : 0.f;
+            int rs = 0, re = len0 - 1;
+            bool done = false;
+            const unsigned long long lo_mask = lane == 0 ? 0ull : (~0ull >> (64 - lane)), hi_mask = lane == 63 ? 0ull : (~0ull << (lane + 1));
+            for (;;) {
+                if (rs >= re) { done = true; break; }
+                n_rounds++;
+                if (re - rs <= 5) {
+                    // the reference's insertion sort of the last <= 6 elements = stable ascending order: rank by comparisons, one scatter
+                    const bool in = lane >= rs && lane <= re;
+                    int rank = 0;
+#pragma unroll
+                    for (int q = 0; q < 6; q++) {
+                        const int pq = min(rs + q, re);
+                        const float wq = __shfl(w, pq, 64);
+                        if (rs + q <= re) rank += (wq < w || (!(w < wq) && pq < lane)) ? 1 : 0;      // (wq == w in the comparison's own sense: neither is below the other)
+                    }
+                    const int dst = in ? rs + rank : lane;
+                    w = __int_as_float(__builtin_amdgcn_ds_permute(dst << 2, __float_as_int(w)));
+                    done = true; break;
+                }
+                if (tries++ == 5) { const int len = re - rs + 1; if (len * 2 > prev) quick = false; prev = len; tries = 0; }
+                if (!quick) break;                                     // no progress: the median-of-medians rounds run on the row in memory
+                const int m = (rs + re) / 2;
+                const float ds = __shfl(w, rs, 64), dm = __shfl(w, m, 64), de = __shfl(w, re, 64);
+                int pi;
+                if (ds < de) pi = dm < ds ? rs : (dm < de ? m : re);
+                else pi = dm < de ? re : (dm < ds ? m : rs);
+                const float piv = pi == rs ? ds : (pi == m ? dm : de);
+                if (pi != rs) { if (lane == pi) w = ds; if (lane == rs) w = piv; }
+                const bool in = lane > rs && lane <= re;
+                const unsigned long long g = __ballot(in && w > piv), l = __ballot(in && w < piv);
+                const int nG = __popcll(g);
+                const bool isg = (g >> lane) & 1ull, isl = (l >> lane) & 1ull;
+                const int g_below = __popcll(g & lo_mask), l_above = __popcll(l & hi_mask);
+                const bool swp = isg ? l_above > g_below : (isl ? g_below > l_above : false);
+                const int t = __popcll(__ballot(swp && isg));
+                // pair i = (i-th '>' from the left, i-th '<' from the right): both lane ids to lane i (the other lanes fill the permutation up)
+                const int dstA = isg ? g_below : nG + __popcll(~g & lo_mask);
+                const int dstB = isl ? l_above : __popcll(l) + __popcll(~l & hi_mask);
+                const int A = __builtin_amdgcn_ds_permute(dstA << 2, lane), B = __builtin_amdgcn_ds_permute(dstB << 2, lane);
+                const int P = A | (B << 8);
+                const int q = __builtin_amdgcn_ds_bpermute((isg ? g_below : l_above) << 2, P);
+                const int partner = isg ? (q >> 8) & 255 : q & 255;
+                const float nv = __int_as_float(__builtin_amdgcn_ds_bpermute((swp ? partner : lane) << 2, __float_as_int(w)));
+                if (swp) w = nv;
+                const int iA = __shfl(B, max(t - 1, 0), 64), iB = __shfl(A, min(t, 63), 64);
+                const float dend = __shfl(w, re, 64);
+                const int hi0 = t > 0 ? iA : re;
+                int lo1 = hi0; bool lo_is_greater;
+                if (t < nG && iB < hi0) { lo1 = iB; lo_is_greater = true; }
+                else lo_is_greater = t > 0 ? true : !(dend < piv);
+                const int sp = lo_is_greater ? lo1 - 1 : lo1;
+                const float vsp = __shfl(w, sp, 64);
+                if (lane == rs) w = vsp;
+                if (lane == sp) w = piv;
+                if (sp < kr) rs = sp + 1; else if (sp > kr) re = sp - 1; else { done = true; break; }
+            }
+            if (lane < len0) d[s0 + lane] = w;
+            (MEM ? wave_sync_mem() : wave_sync_lds());
+            if (done) break;
+            s = s0 + rs; e = s0 + re;                                  // (quick is false from here on: the regime is not entered again)
+        }
+        if (quick && tries++ == 5) { const int len = e - s + 1; if (len * 2 > prev) quick = false; prev = len; tries = 0; }
+        int pi; float piv, dfront;
+        if (st) tq = clock64();
+        if (quick) {
+            // sel_pivot_ends with its three (uniform) reads kept: the pivot's value is one of them
+            const int m = (s + e) / 2;
+            const float ds = d[s], dm = d[m], de = d[e];
+            if (ds < de) pi = dm < ds ? s : (dm < de ? m : e);
+            else pi = dm < de ? e : (dm < ds ? m : s);
+            piv = pi == s ? ds : (pi == m ? dm : de);
+            dfront = ds;
+        } else {
+            int tmp = 0;
+            const unsigned long long t0 = st ? clock64() : 0ull;
+            tmp = wave_median_of_medians<MEM>(d, idx, s, e, lane);      // fallback of a selection that does not make progress: the reference's in-place group medians
+            if (st) { c_mom += clock64() - t0; n_mom++; }
+            pi = tmp;
+            piv = d[pi]; dfront = d[s];
+        }
+        // pivot to the front. No hand-off is needed around it: the three reads above have returned (the pivot's index is computed from
+        // them), the slices below never read d[s], and the one slot they could see too early (d[pi]) is patched in registers.
+        if (!quick) (MEM ? wave_sync_mem() : wave_sync_lds());
+        if (pi != s && lane == 0) { d[pi] = dfront; d[s] = piv; }
+        if (st) { const unsigned long long now = clock64(); c_a += now - tq; tq = now; }
+        // The reference's partition loop pairs the i-th element > pivot from the left with the i-th element < pivot from the right and swaps
+        // them while they have not crossed. Ranks by position: the elements of (s, e] are taken 64 at a time (lane = position within the
+        // slice), so a rank is "set bits of the slice's ballot below my lane + the totals of the slices before" -- no scan, no LDS.
+        const int L = e - s;                                           // elements besides the pivot
+        int nG = 0, nLt = 0;
+        float v4[4]; unsigned long long g4[4], l4[4];                  // the first four slices stay in registers (every row of <= 257 elements)
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            g4[q] = 0ull; l4[q] = 0ull;
+            if (q > 0 && 64 * q >= L) continue;                        // (uniform: short ranges take one slice)
+            const int p = s + 1 + lane + 64 * q;
+            const bool in = p <= e;
+            v4[q] = in ? (p == pi ? dfront : d[p]) : piv;
+            g4[q] = __ballot(in && v4[q] > piv); l4[q] = __ballot(in && v4[q] < piv);
+            nG += __popcll(g4[q]); nLt += __popcll(l4[q]);
+        }
+        for (int base = 256; base < L; base += 256) {                  // longer rows: count the rest, four slices (reads) at a time
+            float v[4];
+#pragma unroll
+            for (int q = 0; q < 4; q++) { const int p = s + 1 + lane + base + 64 * q; v[q] = p <= e ? (p == pi ? dfront : d[p]) : piv; }
+#pragma unroll
+            for (int q = 0; q < 4; q++) { nG += __popcll(__ballot(v[q] > piv)); nLt += __popcll(__ballot(v[q] < piv)); }
+        }
+        // idx[i] = position of the i-th '>' from the left; idx[L-1-i] = position of the i-th '<' from the right (nG + nLt <= L)
+        {
+            int bg = 0, bl = 0;                                        // '>' / '<' met in the slices before
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                if (q > 0 && 64 * q >= L) continue;
+                const int p = s + 1 + lane + 64 * q;
+                const int below_g = (int)__builtin_amdgcn_mbcnt_hi((unsigned)(g4[q] >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)g4[q], 0u));
+                const int below_l = (int)__builtin_amdgcn_mbcnt_hi((unsigned)(l4[q] >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)l4[q], 0u));
+                if ((g4[q] >> lane) & 1ull) idx[bg + below_g] = p;
+                if ((l4[q] >> lane) & 1ull) idx[L - 1 - (nLt - 1 - (bl + below_l))] = p;
+                bg += __popcll(g4[q]); bl += __popcll(l4[q]);
+            }
+            for (int base = 256; base < L; base += 256) {
+                float v[4];
+#pragma unroll
+                for (int q = 0; q < 4; q++) { const int p = s + 1 + lane + base + 64 * q; v[q] = p <= e ? (p == pi ? dfront : d[p]) : piv; }      // (out of range: equal to the pivot, in neither set)
+#pragma unroll
+                for (int q = 0; q < 4; q++) {
+                    const int p = s + 1 + lane + base + 64 * q;
+                    const unsigned long long gm = __ballot(v[q] > piv), lm = __ballot(v[q] < piv);
+                    const int below_g = (int)__builtin_amdgcn_mbcnt_hi((unsigned)(gm >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)gm, 0u));
+                    const int below_l = (int)__builtin_amdgcn_mbcnt_hi((unsigned)(lm >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)lm, 0u));
+                    if ((gm >> lane) & 1ull) idx[bg + below_g] = p;
+                    if ((lm >> lane) & 1ull) idx[L - 1 - (nLt - 1 - (bl + below_l))] = p;
+                    bg += __popcll(gm); bl += __popcll(lm);
+                }
+            }
+        }
+        (MEM ? wave_sync_mem() : wave_sync_lds());
+        if (st) { const unsigned long long now = clock64(); c_b += now - tq; tq = now; }
+        // pair i is swapped iff its two members have not crossed; pairs are disjoint, so one lane per pair is race-free
+        int t = 0;
+        for (int base = 0, m = min(nG, nLt); base < m; base += 64) {
+            const int i = base + lane;
+            const bool act = i < m;
+            const int a_ = act ? idx[i] : 0, b_ = act ? idx[L - 1 - i] : 0;
+            const bool sw = act && a_ < b_;
+            t += __popcll(__ballot(sw));
+            if (sw) { const float va = d[a_]; d[a_] = d[b_]; d[b_] = va; }
+        }
+        (MEM ? wave_sync_mem() : wave_sync_lds());
+        if (st) { const unsigned long long now = clock64(); c_c += now - tq; tq = now; }
+        // where the reference's scan pointers end up, and where the pivot comes to rest (jly_sorting.hpp:282-303); the three reads go out together
+        const int iA = idx[max(L - t, 0)], iB = idx[min(t, L - 1)];
+        const float dend = d[e];
+        const int hi0 = t > 0 ? iA : e;
+        int lo1 = hi0; bool lo_is_greater;
+        if (t < nG && iB < hi0) { lo1 = iB; lo_is_greater = true; }
+        else lo_is_greater = t > 0 ? true : !(dend < piv);            // t == 0: d[e] is untouched; '<' means the pivot swaps with it
+        const int sp = lo_is_greater ? lo1 - 1 : lo1;
+        if (lane == 0) { d[s] = d[sp]; d[sp] = piv; }
+        (MEM ? wave_sync_mem() : wave_sync_lds());
+        if (st) { const unsigned long long now = clock64(); c_d += now - tq; tq = now; }
+        if (sp < k) s = sp + 1; else if (sp > k) e = sp - 1; else break;
+    }
+    (MEM ? wave_sync_mem() : wave_sync_lds());
+    if (st && lane == 0) { atomicAdd(&st[0], 1ull); atomicAdd(&st[1], n_rounds); atomicAdd(&st[2], n_mom); atomicAdd(&st[3], c_mom); atomicAdd(&st[4], c_ins); atomicAdd(&st[5], c_a); atomicAdd(&st[6], c_b); atomicAdd(&st[7], c_c); }
+}
+
+template <int BLOCK>
+struct TileShm {
+    float cube[TC][4];        // x, y, z, w
+    float cen[TC][3];         // centre translation
+    float mtd[TC];            // maxTransDis
+    unsigned hist[TC][1024];  // radix-select histograms (first pass 1024 bins, later passes 256)
+    unsigned prefix[TC];
+    int rem[TC];
+    unsigned maxb[TC];        // bit pattern of the largest residual per cube
+    unsigned wmax[BLOCK / 64][TC];   // per-wave maxima (plain stores: no initialisation to order against)
+    int fallback;
+    int zc[TC];               // residuals that are exactly 0 (clamped), counted with ballots instead of LDS adds
+    int ncand[TC];            // members of the threshold bin collected for the in-wave refinement
+    unsigned cand[TC][CAND_CAP];
+    double red[BLOCK / 64][2 * TC];
+    float ub[TC], lb[TC];
+    float ub2[TC], lb2[TC];   // fused form: bounds of the first of the two calls
+    float lat[NLMAX][3];
+    int cnt[NLMAX];
+    float fpv[NLMAX];
+    int ctl[4];               // [0] done flag, [1] status
+};
+
+// Evaluate the TC cubes whose descriptors sit in sh.cube[] against the PPT points each lane holds in
+// registers. Results: sh.ub[], sh.lb[] (geometric part only; the penalty part is added by the caller).
+// Restates reference jly_goicp.cpp:343-415.
+// NT = cubes of the tile (TC everywhere today; 4-cube tiles with two 512-lane workgroups per CU measured no faster)
+// JIT = true: the lane's points are not held in registers; point m is fetched from `jit_rot` / `jit_rho` just before its gathers
+// (one point ahead), which frees the registers a second workgroup per CU needs (512 lanes x 10 points, k_eval_cubes only).
+// DUAL = true (just-in-time, non-parity form): the tile is evaluated for TWO calls that share rotation and cubes -- the ub-call
+// (no rotation uncertainty) and an lb-call (radius row dual_rho) -- from ONE pass of gathers: results of the first in sh.ub2 / sh.lb2,
+// of the second in sh.ub / sh.lb. OuterBnB's two InnerBnB calls per child rotation (jly_goicp.cpp:768,861) read the same DT cells.
+template <int BLOCK, int PPT, bool OCT, int NT, bool JIT = false, bool DUAL = false, bool XBIG = false /* JIT kernels: the parity_mode 2 instantiation (rows in HBM) */>
+__device__ __forceinline__ void sweep_tile(const DevTables& T, TileShm<BLOCK>& sh, const float (&px)[PPT], const float (&py)[PPT],
+                                           const float (&pz)[PPT], const float (&pw)[PPT], const float (&prho)[PPT], bool use_rho,
+                                           float* rbuf /* LDS, exact mode only */, bool row_mode = false /* !OCT: the cubes share y and z */,
+                                           const float4* __restrict__ jit_rot = nullptr, const float* __restrict__ jit_rho = nullptr,
+                                           const float* lut_lds = nullptr /* LDS copy of T.lut[0, LUT_LDS) or null */,
+                                           const float* __restrict__ dual_rho = nullptr) {
+    const int tid = threadIdx.x;
+    const int Nd = T.Nd;
+    float r[NT][PPT];
+    // gathers: the NT lookups of one point are issued back to back (no consumer in between), so every lane keeps NT loads
+    // in flight. A lookup that leaves the grid only sets a flag bit; its extension length (jly_3ddt.cpp:1150-1187) is
+    // formed on the rare lanes that need it, after the fetch.
+    // Lanes past Nd carry a zero point with zero weight (their residuals are never counted).
+    const int S = T.S;
+    auto cells = [&](float X, float Y, float Z, unsigned (&idx)[NT]) -> unsigned {
+        unsigned oob = 0u;
+        if (OCT) {
+            // the 8 cubes are the 2x2x2 children of one node: child j sits at (j&1, j>>1&1, j>>2&1), so only two distinct
+            // centre coordinates exist per axis and the (double) cell arithmetic is done 6 times instead of 24
+            int rx[2], ry[2], rz[2];
+#pragma unroll
+            for (int q = 0; q < 2; q++) {
+                rx[q] = cell_of(X + sh.cen[q][0], T.xMin, T.scale);
+                ry[q] = cell_of(Y + sh.cen[2 * q][1], T.yMin, T.scale);
+                rz[q] = cell_of(Z + sh.cen[4 * q][2], T.zMin, T.scale);
+            }
+#pragma unroll
+            for (int j = 0; j < NT; j++) {
+                const int x = rx[j & 1], y = ry[j >> 1 & 1], z = rz[j >> 2 & 1];
+                idx[j] = (unsigned)((clamp_cell(z, S) * S + clamp_cell(y, S)) * S + clamp_cell(x, S));
+                oob |= ((((unsigned)x >= (unsigned)S) | ((unsigned)y >= (unsigned)S) | ((unsigned)z >= (unsigned)S)) ? 1u : 0u) << j;
+            }
+        } else if (row_mode) {
+            // the 8 cubes form a row (same y and z centre, e.g. 8 x-neighbours of a level grid): the y and z cell
+            // arithmetic is shared, 10 axis computations instead of 24
+            const int y = cell_of(Y + sh.cen[0][1], T.yMin, T.scale), z = cell_of(Z + sh.cen[0][2], T.zMin, T.scale);
+            const int rowbase = (clamp_cell(z, S) * S + clamp_cell(y, S)) * S;
+            const unsigned yz_out = (((unsigned)y >= (unsigned)S) | ((unsigned)z >= (unsigned)S)) ? 1u : 0u;
+#pragma unroll
+            for (int j = 0; j < NT; j++) {
+                const int x = cell_of(X + sh.cen[j][0], T.xMin, T.scale);
+                idx[j] = (unsigned)(rowbase + clamp_cell(x, S));
+                oob |= (yz_out | (((unsigned)x >= (unsigned)S) ? 1u : 0u)) << j;
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < NT; j++) {
+                const int x = cell_of(X + sh.cen[j][0], T.xMin, T.scale), y = cell_of(Y + sh.cen[j][1], T.yMin, T.scale), z = cell_of(Z + sh.cen[j][2], T.zMin, T.scale);
+                idx[j] = (unsigned)((clamp_cell(z, S) * S + clamp_cell(y, S)) * S + clamp_cell(x, S));
+                oob |= ((((unsigned)x >= (unsigned)S) | ((unsigned)y >= (unsigned)S) | ((unsigned)z >= (unsigned)S)) ? 1u : 0u) << j;
+            }
+        }
+        return oob;
+    };
+    // diagnosis (build with -DGOICP_TILE_STAMPS, run with GOICP_DBG & 64; tools/tile_phases.py): cycle stamps of wave 0 / lane 0 of every 64th
+    // workgroup, summed into T.dbg_times[0..7]. Compiled out by default: the stamp state costs the metric kernel registers it does not have.
+#ifdef GOICP_TILE_STAMPS
+    const bool stamp = DBG_ON(T, 64) && T.dbg_times && tid == 0 && (blockIdx.x & 63) == 0;
+    unsigned long long tl_ = stamp ? clock64() : 0ull;
+#define TSTAMP(k) do { if (stamp) { const unsigned long long now_ = clock64(); atomicAdd(&T.dbg_times[k], now_ - tl_); tl_ = now_; } } while (0)
+#else
+    constexpr bool stamp = false;
+#define TSTAMP(k) do { } while (0)
+#endif
+    float4 pnext = make_float4(0.f, 0.f, 0.f, 0.f); float rnext = 0.f;
+    if (JIT) { const int i0 = min(tid, Nd - 1); pnext = jit_rot[i0]; rnext = jit_rho ? jit_rho[i0] : 0.f; }
+#pragma unroll
+    for (int m = 0; m < PPT; m++) {
+        float X, Y, Z, W, RH;
+        if (JIT) {
+            X = pnext.x; Y = pnext.y; Z = pnext.z; W = pnext.w; RH = rnext;
+            if (m + 1 < PPT) { const int in = min(tid + (m + 1) * BLOCK, Nd - 1); pnext = jit_rot[in]; rnext = jit_rho ? jit_rho[in] : 0.f; }
+        } else { X = px[m]; Y = py[m]; Z = pz[m]; W = pw[m]; RH = prho[m]; }
+        unsigned idx[NT]; float v[NT];
+        const unsigned oob = cells(X, Y, Z, idx);
+        if (T.code) {
+            // coded grid: 2-byte gathers (half the cache lines of the float grid), then the value from the LUT
+            unsigned c[NT];
+#pragma unroll
+            for (int j = 0; j < NT; j++) c[j] = T.code[DBG_ON(T, 2) ? (idx[j] & 1023u) : idx[j]];
+#pragma unroll
+            for (int j = 0; j < NT; j++) v[j] = dt_decode(T, idx[j], c[j], lut_lds);
+        } else {
+#pragma unroll
+            for (int j = 0; j < NT; j++) v[j] = T.dist[DBG_ON(T, 2) ? (idx[j] & 1023u) : idx[j]];
+        }
+        if (__any((int)oob)) {
+#pragma unroll
+            for (int j = 0; j < NT; j++) {
+                if ((oob >> j) & 1u) {
+                    float ext; (void)dt_index(T, X + sh.cen[j][0], Y + sh.cen[j][1], Z + sh.cen[j][2], ext);
+                    v[j] = dt_finish(T, v[j], ext);
+                }
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < NT; j++) {
+            float d = W * v[j];
+            if (use_rho) d -= RH;
+            if (d < 0.f) d = 0.f;
+            if (JIT) asm volatile("" : "+v"(d));           // the residual is formed HERE (otherwise the compiler may sink these operations to the
+            r[j][m] = d;                                   // first use and keep value, weight and radius alive instead: registers, spills)
+        }
+        if (JIT) __builtin_amdgcn_sched_barrier(0);        // keep the point fetches one ahead instead of all up front
+    }
+    TSTAMP(0);
+    // everything behind the gathers (selection + sums -> sh.ub / sh.lb) as one block, so that the fused form can run it twice on the same
+    // distance values: first for the call without rotation uncertainty, then again after subtracting the radius of the other call
+    auto finish = [&]() __attribute__((always_inline)) {      // (out of line the residual registers would go through scratch memory)
+    // (the just-in-time kernels carry the reference-order branches only in their parity_mode 2 instantiation: beside the fast path they cost it registers)
+    if ((JIT ? XBIG : (BLOCK * PPT <= 1024 && T.exact)) && T.doTrim) {
+        // parity mode, trimmed: residual rows to LDS, one lane per cube runs the reference's selection (same swaps, same final
+        // order), then the inlier sums are taken sequentially in float over that order -- bit-exact with jly_goicp.cpp:384-415
+#pragma unroll
+        for (int m = 0; m < PPT; m++) {
+            const int i = tid + m * BLOCK;
+            if (i < Nd) {
+#pragma unroll
+                for (int j = 0; j < NT; j++) rbuf[j * Nd + i] = r[j][m];
+            }
+        }
+        __syncthreads();
+        for (int j = tid >> 6; j < NT; j += BLOCK / 64)
+            wave_intro_select<JIT>(rbuf + j * Nd, reinterpret_cast<int*>(rbuf + NT * Nd) + j * Nd, Nd, T.inlierNum - 1, tid & 63, DBG_ON(T, 32) && T.dbg_times ? T.dbg_times + 8 : nullptr, (T.dbg & 256) != 0);      // (JIT: rows in HBM)
+        __syncthreads();
+        if (tid < 2 * NT) {
+            const int j = tid & (NT - 1);
+            const bool is_lb = tid >= NT;
+            const float* rr = rbuf + j * Nd;
+            const float sub = is_lb ? sh.mtd[j] : 0.f;
+            const bool sq = T.norm == 2, lin = T.norm == 1;
+            float acc = 0.f;
+            auto add = [&](float d) {
+                const float e = d - sub;                           // (d - 0 == d exactly for the ub chain)
+                float term = sq ? e * e : (lin ? e : 0.f);
+                if (is_lb && !(e > 0.f)) term = 0.f;
+                acc += term;
+            };
+            int i = 0;
+            for (; i + 16 <= T.inlierNum; i += 16) {                // 16 LDS reads in flight, then the 16 dependent adds
+                float v[16];
+#pragma unroll
+                for (int q = 0; q < 16; q++) v[q] = rr[i + q];
+#pragma unroll
+                for (int q = 0; q < 16; q++) add(v[q]);
+            }
+            for (; i < T.inlierNum; i++) add(rr[i]);
+            if (is_lb) sh.lb[j] = acc; else sh.ub[j] = acc;
+        }
+        __syncthreads();
+        return;
+    }
+    if ((JIT ? XBIG : T.exact != 0) && !T.doTrim) {
+        // reference order: float, sequential over the point index (bit-exact with jly_goicp.cpp:393-415). Every lane first
+        // turns its residuals into the two addends (d*d and max(d-mtd,0)^2, or the norm-1 forms) in parallel; 16 lanes then
+        // run the 16 sequential float sums (8 ub chains, 8 lb chains), one add per element. Skipping a term (e <= 0) and
+        // adding +0.0f leave the same bits because the running sums are never negative.
+        float* tub = rbuf; float* tlb = rbuf + NT * Nd;
+        const bool sq = T.norm == 2, lin = T.norm == 1;
+#pragma unroll
+        for (int m = 0; m < PPT; m++) {
+            const int i = tid + m * BLOCK;
+            if (i < Nd) {
+#pragma unroll
+                for (int j = 0; j < NT; j++) {
+                    const float d = r[j][m], e = d - sh.mtd[j];
+                    tub[j * Nd + i] = sq ? d * d : (lin ? d : 0.f);
+                    tlb[j * Nd + i] = e > 0.f ? (sq ? e * e : (lin ? e : 0.f)) : 0.f;
+                }
+            }
+        }
+        __syncthreads();
+        if (tid < 2 * NT) {
+            const float* tt = rbuf + tid * Nd;          // lanes 0-7: ub rows, lanes 8-15: lb rows
+            float acc = 0.f;
+            int i = 0;
+            for (; i + 16 <= Nd; i += 16) {
+                float v[16];
+#pragma unroll
+                for (int q = 0; q < 16; q++) v[q] = tt[i + q];
+#pragma unroll
+                for (int q = 0; q < 16; q++) acc += v[q];
+            }
+            for (; i < Nd; i++) acc += tt[i];
+            if (tid < NT) sh.ub[tid] = acc; else sh.lb[tid - NT] = acc;
+        }
+        __syncthreads();
+        return;
+    }
+    // ---- inlier threshold per cube = the inlierNum-th smallest residual, by MSB-first radix select on the float bit
+    //      pattern (residuals are >= 0, so the pattern orders like the value) with LDS histograms. Replaces intro_select
+    //      (reference jly_sorting.hpp:229): the selected multiset is the same, the order is not needed (order-free sums).
+    unsigned thr[NT]; int below[NT];
+#pragma unroll
+    for (int j = 0; j < NT; j++) { thr[j] = 0u; below[j] = 0; }
+    if (T.doTrim && !DBG_ON(T, 1)) {
+        const int wv = tid >> 6, ln = tid & 63;
+        constexpr int NW = BLOCK / 64;
+        // Five workgroup barriers for the whole selection + sums. Everything initialised here is first used after barrier 1.
+        for (int k = tid; k < NT * 1024; k += BLOCK) (&sh.hist[0][0])[k] = 0u;
+        if (tid < NT) { sh.prefix[tid] = 0u; sh.rem[tid] = T.inlierNum - 1; sh.zc[tid] = 0; sh.ncand[tid] = 0; }
+        if (tid == 0) sh.fallback = 0;
+        // (1) largest residual per cube (fixes the 8-octave window of the histogram): per-wave maxima by plain stores
+#pragma unroll
+        for (int j = 0; j < NT; j++) {
+            unsigned mx = 0u;
+#pragma unroll
+            for (int m = 0; m < PPT; m++) if (tid + m * BLOCK < Nd) mx = max(mx, __float_as_uint(r[j][m]));
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) mx = max(mx, (unsigned)__shfl_down((int)mx, off, 64));
+            if (ln == 0) sh.wmax[wv][j] = mx;
+        }
+        __syncthreads();                                                            // barrier 1
+        TSTAMP(1);
+        int base16[NT];
+#pragma unroll
+        for (int j = 0; j < NT; j++) {
+            unsigned mx = ln < NW ? sh.wmax[ln][j] : 0u;
+#pragma unroll
+            for (int off = 8; off > 0; off >>= 1) mx = max(mx, (unsigned)__shfl_xor((int)mx, off, 64));   // NW <= 16
+            mx = (unsigned)__shfl((int)mx, 0, 64);
+            base16[j] = max(0, (int)(mx >> 16) - 1023);
+            if (tid == j) sh.maxb[j] = mx;
+        }
+        // (2) ONE histogram pass: 10-bit digit = top 16 bits (sign, exponent, 7 mantissa bits) relative to the cube's maximum:
+        //     1024 monotone bins over the 8 octaves below the maximum, so the values spread over hundreds of LDS words
+        //     instead of piling onto the 2-3 exponent bytes a plain byte pass would see. Residuals clamped to exactly 0
+        //     (frequent once a rotation-uncertainty radius is subtracted) are bit-identical and would serialise on one
+        //     LDS word, so they are counted with ballots and kept out of the histogram.
+#pragma unroll
+        for (int j = 0; j < NT; j++) {
+            int z = 0;
+#pragma unroll
+            for (int m = 0; m < PPT; m++) {
+                const bool valid = tid + m * BLOCK < Nd;
+                const unsigned bits = __float_as_uint(r[j][m]);
+                z += __popcll(__ballot(valid && bits == 0u));
+                if (valid && bits != 0u) atomicAdd(&sh.hist[j][max(0, (int)(bits >> 16) - base16[j])], 1u);
+            }
+            if (ln == 0 && z) atomicAdd(&sh.zc[j], z);
+        }
+        __syncthreads();                                                            // barrier 2
+        TSTAMP(2);
+        for (int j = wv; j < NT; j += NW) {             // (3) one wave scans the 1024 bins of a cube: 16 per lane
+            unsigned c[16]; int mine = 0;
+#pragma unroll
+            for (int q = 0; q < 16; q++) { c[q] = sh.hist[j][16 * ln + q]; mine += (int)c[q]; }
+            int incl = mine;
+#pragma unroll
+            for (int off = 1; off < 64; off <<= 1) { const int t = __shfl_up(incl, off, 64); if (ln >= off) incl += t; }
+            const int zc = sh.zc[j];
+            const int rank = sh.rem[j];
+            if (rank < zc) {                                  // the threshold is one of the zeros
+                if (ln == 0) { sh.prefix[j] = 0u; sh.rem[j] = rank; sh.ncand[j] = -1; }
+                continue;
+            }
+            const int rem = rank - zc;
+            const unsigned long long over = __ballot(incl > rem);
+            const int owner = over ? __ffsll((long long)over) - 1 : 63;
+            if (ln == owner) {
+                int rr = rem - (incl - mine);
+                int b = 0;
+#pragma unroll
+                for (int q = 0; q < 15; q++) { if (b == q && rr >= (int)c[q]) { rr -= (int)c[q]; b = q + 1; } }
+                unsigned cb = c[0];
+#pragma unroll
+                for (int q = 1; q < 16; q++) if (b == q) cb = c[q];
+                const int bin = 16 * ln + b;
+                const int b16 = max(0, (int)(sh.maxb[j] >> 16) - 1023);
+                // threshold below the window, or a crowded bin: the generic byte passes decide
+                if ((bin == 0 && b16 > 0) || cb > CAND_CAP) sh.fallback = 1;
+                sh.prefix[j] = (unsigned)(b16 + bin) << 16;
+                sh.rem[j] = rr;                               // rank among the members of the threshold bin
+            }
+        }
+        __syncthreads();                                                            // barrier 3
+        TSTAMP(3);
+        if (!sh.fallback) {
+            // (4) one pass over the registers: everything below the threshold bin goes into the sums (lane-local float partials
+            //     of <= PPT addends, fp64 across lanes), the bin's members (a handful) into the candidate list
+#pragma unroll
+            for (int j = 0; j < NT; j++) {
+                const unsigned p16 = sh.prefix[j] >> 16;
+                const bool known = sh.ncand[j] < 0;           // threshold already known (zero): nothing below it
+                const float mtd = sh.mtd[j];
+                float fub = 0.f, flb = 0.f;
+#pragma unroll
+                for (int m = 0; m < PPT; m++) {
+                    const float d = r[j][m];
+                    const unsigned bits = __float_as_uint(d);
+                    const bool valid = tid + m * BLOCK < Nd && bits != 0u;      // zeros add nothing to either sum
+                    const unsigned b16 = bits >> 16;
+                    const bool in = valid && b16 < p16;
+                    const float e = d - mtd;
+                    const float tu = T.norm == 2 ? d * d : (T.norm == 1 ? d : 0.f);
+                    const float tl = T.norm == 2 ? e * e : (T.norm == 1 ? e : 0.f);
+                    fub += in ? tu : 0.f;
+                    flb += (in && e > 0.f) ? tl : 0.f;
+                    if (valid && !known && b16 == p16) { const int pos = atomicAdd(&sh.ncand[j], 1); if (pos < CAND_CAP) sh.cand[j][pos] = bits; }
+                }
+                const double u = wave_sum((double)fub), l = wave_sum((double)flb);
+                if (ln == 0) { sh.red[wv][2 * j] = u; sh.red[wv][2 * j + 1] = l; }
+            }
+            __syncthreads();                                                        // barrier 4
+            TSTAMP(4);
+            // (5) wave j finishes cube j: low 16 bits of the threshold by bisection over the candidates, the candidates below it and
+            //     the copies of the threshold that belong to the inlier set join the partial sums of all waves
+            for (int j = wv; j < NT; j += NW) {
+                const int nc = sh.ncand[j];
+                const float mtd = sh.mtd[j];
+                unsigned pre = sh.prefix[j]; int remj = sh.rem[j];
+                double cu = 0.0, cl = 0.0;
+                if (nc >= 0) {
+                    const bool v0 = ln < nc, v1 = ln + 64 < nc;
+                    const unsigned c0 = v0 ? sh.cand[j][ln] : 0u, c1 = v1 ? sh.cand[j][ln + 64] : 0u;
+#pragma unroll
+                    for (int b = 15; b >= 0; b--) {
+                        const unsigned cnd = pre | (1u << b);
+                        const int cnt = __popcll(__ballot(v0 && c0 < cnd)) + __popcll(__ballot(v1 && c1 < cnd));
+                        if (cnt <= remj) pre = cnd;               // the rem-th member is >= cnd
+                    }
+                    const int less = __popcll(__ballot(v0 && c0 < pre)) + __popcll(__ballot(v1 && c1 < pre));
+                    remj -= less;                                 // rank among the copies of the threshold
+                    // (a lane's two candidate terms are added in double: which members of the bin share a lane depends on the order of the LDS
+                    // adds that collected them, and a float sum of two terms would round differently from run to run)
+                    if (v0 && c0 < pre) { const float d = __uint_as_float(c0), e = d - mtd; cu += (double)(T.norm == 2 ? d * d : (T.norm == 1 ? d : 0.f)); if (e > 0.f) cl += (double)(T.norm == 2 ? e * e : (T.norm == 1 ? e : 0.f)); }
+                    if (v1 && c1 < pre) { const float d = __uint_as_float(c1), e = d - mtd; cu += (double)(T.norm == 2 ? d * d : (T.norm == 1 ? d : 0.f)); if (e > 0.f) cl += (double)(T.norm == 2 ? e * e : (T.norm == 1 ? e : 0.f)); }
+                }
+                // partial sums of all waves (lane w holds wave w's), plus this wave's candidate terms
+                cu += ln < NW ? sh.red[ln][2 * j] : 0.0;
+                cl += ln < NW ? sh.red[ln][2 * j + 1] : 0.0;
+                double u = wave_sum(cu), l = wave_sum(cl);
+                if (ln == 0) {
+                    const float d = __uint_as_float(pre);
+                    const float e = d - mtd;
+                    const double n = (double)(remj + 1);          // copies of the threshold inside the inlier set
+                    if (T.norm == 2) { u += n * (double)(d * d); if (e > 0.f) l += n * (double)(e * e); }
+                    else if (T.norm == 1) { u += n * (double)d; if (e > 0.f) l += n * (double)e; }
+                    sh.ub[j] = (float)u; sh.lb[j] = (float)l;
+                }
+            }
+            __syncthreads();                                                        // barrier 5
+            TSTAMP(5);
+            if (stamp) atomicAdd(&T.dbg_times[7], 1ull);
+            return;
+        }
+        const bool generic = sh.fallback != 0;
+        if (generic) { if (tid < NT) { sh.prefix[tid] = 0u; sh.rem[tid] = T.inlierNum - 1; } }
+        // (4) generic path: four byte passes, MSB first, when the window missed or a bin was crowded
+        for (int pass = generic ? 3 : -1; pass >= 0; pass--) {
+            __syncthreads();
+            for (int k = tid; k < NT * 256; k += BLOCK) sh.hist[k >> 8][k & 255] = 0u;
+            __syncthreads();
+            const unsigned himask = pass == 3 ? 0u : (0xFFFFFFFFu << (8 * (pass + 1)));
+#pragma unroll
+            for (int m = 0; m < PPT; m++) {
+                const bool valid = tid + m * BLOCK < Nd;
+#pragma unroll
+                for (int j = 0; j < NT; j++) {
+                    const unsigned bits = __float_as_uint(r[j][m]);
+                    const bool take = valid && ((bits ^ sh.prefix[j]) & himask) == 0u;
+                    hist_add(sh.hist[j], (bits >> (8 * pass)) & 255u, take, ln);
+                }
+            }
+            __syncthreads();
+            for (int j = wv; j < NT; j += BLOCK / 64) {
+                const unsigned c0 = sh.hist[j][4 * ln], c1 = sh.hist[j][4 * ln + 1], c2 = sh.hist[j][4 * ln + 2], c3 = sh.hist[j][4 * ln + 3];
+                const int mine = (int)(c0 + c1 + c2 + c3);
+                int incl = mine;
+#pragma unroll
+                for (int off = 1; off < 64; off <<= 1) { const int t = __shfl_up(incl, off, 64); if (ln >= off) incl += t; }
+                const int rem = sh.rem[j];
+                const unsigned long long over = __ballot(incl > rem);
+                const int owner = over ? __ffsll((long long)over) - 1 : 63;
+                if (ln == owner) {
+                    int rr = rem - (incl - mine);
+                    unsigned dgt = 4u * ln;
+                    if (rr >= (int)c0) { rr -= (int)c0; dgt++; if (rr >= (int)c1) { rr -= (int)c1; dgt++; if (rr >= (int)c2) { rr -= (int)c2; dgt++; } } }
+                    sh.prefix[j] |= dgt << (8 * pass);
+                    sh.rem[j] = rr;
+                }
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < NT; j++) { thr[j] = sh.prefix[j]; below[j] = T.inlierNum - 1 - sh.rem[j]; }   // rem = rank among the copies of thr
+    }
+    // ---- sums in fp64 (order-free), float at the end; one cube at a time to keep registers low
+    const int wave = tid >> 6, lane = tid & 63;
+#pragma unroll
+    for (int j = 0; j < NT; j++) {
+        // a lane's own PPT addends are summed in float (PPT <= 16 terms), everything across lanes in fp64
+        float fub = 0.f, flb = 0.f;
+        const float mtd = sh.mtd[j];
+        const unsigned thrj = thr[j];
+#pragma unroll
+        for (int m = 0; m < PPT; m++) {
+            const float d = r[j][m];
+            const bool in = (tid + m * BLOCK < Nd) && (!T.doTrim || __float_as_uint(d) < thrj);
+            const float e = d - mtd;
+            const float tu = T.norm == 2 ? d * d : (T.norm == 1 ? d : 0.f);
+            const float tl = T.norm == 2 ? e * e : (T.norm == 1 ? e : 0.f);
+            fub += in ? tu : 0.f;
+            flb += (in && e > 0.f) ? tl : 0.f;
+        }
+        const double u = wave_sum((double)fub), l = wave_sum((double)flb);
+        if (lane == 0) { sh.red[wave][2 * j] = u; sh.red[wave][2 * j + 1] = l; }
+    }
+    __syncthreads();
+    // every lane holds thr[]/below[] (wave-uniform); lane j finishes cube j
+#pragma unroll
+    for (int j = 0; j < NT; j++) {
+        if (tid == j) {
+            double u = 0.0, l = 0.0;
+            for (int w = 0; w < BLOCK / 64; w++) { u += sh.red[w][2 * j]; l += sh.red[w][2 * j + 1]; }
+            if (T.doTrim) {
+                // the copies of the threshold value that belong to the inlier set
+                const float d = __uint_as_float(thr[j]);
+                const float e = d - sh.mtd[j];
+                const double n = (double)(T.inlierNum - below[j]);
+                if (T.norm == 2) { u += n * (double)(d * d); if (e > 0.f) l += n * (double)(e * e); }
+                else if (T.norm == 1) { u += n * (double)d; if (e > 0.f) l += n * (double)e; }
+            }
+            sh.ub[j] = (float)u; sh.lb[j] = (float)l;
+        }
+    }
+    __syncthreads();
+    };
+    finish();
+    if constexpr (DUAL) {
+        // (two call sites rather than a loop: inside a loop the compiler hoists the block's lane-constant addresses and spills the residuals)
+        if (tid < NT) { sh.ub2[tid] = sh.ub[tid]; sh.lb2[tid] = sh.lb[tid]; }        // (ordered by the barriers of the next finish())
+        // second bound of the same cubes: minDis -= maxRotDisL; clamp (reference jly_goicp.cpp:375-381) on the products weights*DT kept in r
+        int tid2 = tid;
+        asm volatile("" : "+v"(tid2));                     // (keeps the radius fetches below the first finish(): hoisted above it they cost PPT registers)
+#pragma unroll
+        for (int m = 0; m < PPT; m++) {
+            const float rh = dual_rho[min(tid2 + m * BLOCK, Nd - 1)];
+#pragma unroll
+            for (int j = 0; j < NT; j++) { float d = r[j][m] - rh; if (d < 0.f) d = 0.f; r[j][m] = d; }
+        }
+        finish();
+    }
+}
+
+#undef TSTAMP
+
+// Penalty terms at the nl translations in sh.lat[]: incompatibility counts (checkCompatibilities, reference
+// jly_goicp.cpp:919-928) into sh.cnt[], c-FPFH means (sumFPFH, jly_goicp.cpp:1689-1697) into sh.fpv[].
+template <int BLOCK, int PPT>
+__device__ __forceinline__ void lattice_terms(const DevTables& T, TileShm<BLOCK>& sh, int nl, const float (&px)[PPT], const float (&py)[PPT],
+                                              const float (&pz)[PPT], float* fpbuf /* global scratch [NLMAX*Nd] */, bool do_compat = true) {
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int Nd = T.Nd;
+    if (T.use_compat && do_compat) {
+        for (int l = tid; l < nl; l += BLOCK) sh.cnt[l] = 0;
+        __syncthreads();
+        unsigned cls[PPT];
+#pragma unroll
+        for (int m = 0; m < PPT; m++) cls[m] = (tid + m * BLOCK < Nd) ? (unsigned)T.dcls[tid + m * BLOCK] : 0u;
+        for (int l = 0; l < nl; l++) {
+            const float lx = sh.lat[l][0], ly = sh.lat[l][1], lz = sh.lat[l][2];
+            int wave_cnt = 0;
+#pragma unroll
+            for (int m = 0; m < PPT; m++) {
+                bool bad = false;
+                if (tid + m * BLOCK < Nd) {
+                    unsigned mask = T.cmask[clamped_cell(T, px[m] + lx, py[m] + ly, pz[m] + lz)];
+                    bad = ((mask >> cls[m]) & 1u) == 0u;
+                }
+                wave_cnt += __popcll(__ballot(bad));
+            }
+            if (lane == 0 && wave_cnt) atomicAdd(&sh.cnt[l], wave_cnt);
+        }
+        __syncthreads();
+    }
+    if (T.use_fpfh) {
+        for (int l = 0; l < nl; l++) {
+            const float lx = sh.lat[l][0], ly = sh.lat[l][1], lz = sh.lat[l][2];
+#pragma unroll
+            for (int m = 0; m < PPT; m++) {
+                const int i = tid + m * BLOCK;
+                if (i < Nd) fpbuf[(size_t)l * Nd + i] = fpfh_min(T, i, px[m] + lx, py[m] + ly, pz[m] + lz);
+            }
+        }
+        __syncthreads();
+        // the mean is truncated to int by the caller (reference jly_goicp.cpp:468,495), so the float sum must
+        // round exactly like the reference's: sequential over the point index
+        for (int l = tid; l < nl; l += BLOCK) {
+            const float* f = fpbuf + (size_t)l * Nd;
+            float s = 0.f;
+            for (int i = 0; i < Nd; i++) s += f[i];
+            sh.fpv[l] = s / (float)Nd;
+        }
+        __syncthreads();
+    }
+}
+
+// Incompatibility counts at the 27 points of the 3x3x3 corner lattice of a node's children (k_inner_bnb).
+// Lattice point l = a + 3b + 9c has coordinates (X[a], Y[b], Z[c]), so the (double) cell arithmetic is done 9 times
+// per data point instead of 81, and the 27 mask gathers of a point are issued together before any of them is used.
+template <int BLOCK, int PPT>
+__device__ __forceinline__ void lattice_compat_oct(const DevTables& T, TileShm<BLOCK>& sh, const float (&px)[PPT], const float (&py)[PPT], const float (&pz)[PPT]) {
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int Nd = T.Nd, S = T.S;
+    if (tid < 27) sh.cnt[tid] = 0;
+    __syncthreads();
+    int wc[27];
+#pragma unroll
+    for (int l = 0; l < 27; l++) wc[l] = 0;
+#pragma unroll
+    for (int m = 0; m < PPT; m++) {
+        const int i = min(tid + m * BLOCK, Nd - 1);
+        const bool valid = tid + m * BLOCK < Nd;
+        const unsigned cls = (unsigned)T.dcls[i];
+        int cx[3], cy[3], cz[3];
+#pragma unroll
+        for (int a = 0; a < 3; a++) {
+            cx[a] = min(max(cell_of(px[m] + sh.lat[a][0], T.xMin, T.scale), 0), S - 1);
+            cy[a] = min(max(cell_of(py[m] + sh.lat[3 * a][1], T.yMin, T.scale), 0), S - 1);
+            cz[a] = min(max(cell_of(pz[m] + sh.lat[9 * a][2], T.zMin, T.scale), 0), S - 1);
+        }
+        unsigned mk[27];
+#pragma unroll
+        for (int l = 0; l < 27; l++) mk[l] = T.cmask[(size_t)((cz[l / 9] * S + cy[(l / 3) % 3]) * S + cx[l % 3])];
+#pragma unroll
+        for (int l = 0; l < 27; l++) wc[l] += __popcll(__ballot(valid && ((mk[l] >> cls) & 1u) == 0u));
+    }
+    if (lane == 0) {
+#pragma unroll
+        for (int l = 0; l < 27; l++) if (wc[l]) atomicAdd(&sh.cnt[l], wc[l]);
+    }
+    __syncthreads();
+}
+
+// c-FPFH means at the 27 points of the children's corner lattice (k_inner_bnb). Per data point: 9 axis computations,
+// the 27 nearest-occupied-cell ids fetched together, the point's own descriptor row held in registers, and a lattice
+// point that resolves to the same occupied cell as its predecessor reuses the predecessor's minimum (frequent at deep
+// levels, where the lattice spacing is below the cell size). The per-lattice-point mean is then summed sequentially in
+// float (the reference truncates it to int, so it must round the same way) from rows kept in LDS when they fit.
+template <int BLOCK, int PPT>
+__device__ __forceinline__ void lattice_fpfh_oct(const DevTables& T, TileShm<BLOCK>& sh, const float (&px)[PPT], const float (&py)[PPT], const float (&pz)[PPT],
+                                                 float* rows /* [27*Nd], LDS or global */) {
+    const int tid = threadIdx.x;
+    const int Nd = T.Nd, S = T.S;
+#pragma unroll
+    for (int m = 0; m < PPT; m++) {
+        const int i = min(tid + m * BLOCK, Nd - 1);
+        const bool valid = tid + m * BLOCK < Nd;
+        int cx[3], cy[3], cz[3];
+#pragma unroll
+        for (int a = 0; a < 3; a++) {
+            cx[a] = min(max(cell_of(px[m] + sh.lat[a][0], T.xMin, T.scale), 0), S - 1);
+            cy[a] = min(max(cell_of(py[m] + sh.lat[3 * a][1], T.yMin, T.scale), 0), S - 1);
+            cz[a] = min(max(cell_of(pz[m] + sh.lat[9 * a][2], T.zMin, T.scale), 0), S - 1);
+        }
+        int o[27];
+#pragma unroll
+        for (int l = 0; l < 27; l++) o[l] = T.occ[(size_t)((cz[l / 9] * S + cy[(l / 3) % 3]) * S + cx[l % 3])];
+        float v[27];
+        const float* Erow = T.fpE + (size_t)i * T.nOcc;
+#pragma unroll
+        for (int l = 0; l < 27; l++) v[l] = Erow[max(o[l], 0)];            // 27 gathers in flight
+#pragma unroll
+        for (int l = 0; l < 27; l++) if (valid) rows[(size_t)l * Nd + i] = o[l] < 0 ? 1000000000.f : v[l];
+    }
+    __syncthreads();
+    if (tid < 27) {
+        const float* fr = rows + (size_t)tid * Nd;
+        float acc = 0.f;
+        int i = 0;
+        for (; i + 16 <= Nd; i += 16) {
+            float v[16];
+#pragma unroll
+            for (int q = 0; q < 16; q++) v[q] = fr[i + q];
+#pragma unroll
+            for (int q = 0; q < 16; q++) acc += v[q];
+        }
+        for (; i < Nd; i++) acc += fr[i];
+        sh.fpv[tid] = acc / (float)Nd;
+    }
+    __syncthreads();
+}
+
+// ---------------------------------------------------------------------------------------------
+// pop_eval_fused: everything a queue pop of a cavity-sized search evaluates (k_inner_bnb, parity mode, untrimmed, penalty terms) in ONE
+// gather phase and ONE sequential-sum phase. sweep_tile + lattice_compat_oct + lattice_fpfh_oct do the same work as three phases of their
+// own (gathers -> barrier -> 16 / 27 sequential chains -> barrier, three times over: 7.2 k + 7.9 k + 13.6 k cycles of a 40 k-cycle pop at 238
+// points). Here a point's 8 distance lookups, 27 compatibility masks and 27 nearest-occupied-cell ids are in flight together (then the 27
+// table entries), the addends / c-FPFH rows go to LDS, and after one barrier the 16 bound chains (wave 0) and the 27 c-FPFH chains (wave 1)
+// run side by side. Same values, same order of every float sum: same bits (reference jly_goicp.cpp:343-415, 431-550, 919-928, 1642-1697).
+// Expects sh.cube / sh.cen / sh.mtd / sh.lat set and sh.cnt[0..26] zeroed behind a barrier.
+// ---------------------------------------------------------------------------------------------
+template <int BLOCK, int PPT>
+__device__ __forceinline__ void pop_eval_fused(const DevTables& T, TileShm<BLOCK>& sh, const float (&px)[PPT], const float (&py)[PPT], const float (&pz)[PPT],
+                                               const float (&pw)[PPT], const float (&prho)[PPT], bool use_rho, float* rbuf /* LDS: 2 x TC x Nd addends */,
+                                               float* fprows /* [27 x Nd], LDS or global */) {
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int Nd = T.Nd, S = T.S;
+    const bool sq = T.norm == 2, lin = T.norm == 1;
+    float* tub = rbuf; float* tlb = rbuf + TC * Nd;
+    int wc[27];
+#pragma unroll
+    for (int l = 0; l < 27; l++) wc[l] = 0;
+#pragma unroll
+    for (int m = 0; m < PPT; m++) {
+        const int i = tid + m * BLOCK;
+        const bool valid = i < Nd;
+        const int ic = min(i, Nd - 1);
+        const float X = px[m], Y = py[m], Z = pz[m];
+        // children: two centre coordinates per axis (sweep_tile, OCT)
+        int rx[2], ry[2], rz[2];
+#pragma unroll
+        for (int q = 0; q < 2; q++) {
+            rx[q] = cell_of(X + sh.cen[q][0], T.xMin, T.scale);
+            ry[q] = cell_of(Y + sh.cen[2 * q][1], T.yMin, T.scale);
+            rz[q] = cell_of(Z + sh.cen[4 * q][2], T.zMin, T.scale);
+        }
+        unsigned idx[TC]; unsigned oob = 0u;
+#pragma unroll
+        for (int j = 0; j < TC; j++) {
+            const int x = rx[j & 1], y = ry[j >> 1 & 1], z = rz[j >> 2 & 1];
+            idx[j] = (unsigned)((clamp_cell(z, S) * S + clamp_cell(y, S)) * S + clamp_cell(x, S));
+            oob |= ((((unsigned)x >= (unsigned)S) | ((unsigned)y >= (unsigned)S) | ((unsigned)z >= (unsigned)S)) ? 1u : 0u) << j;
+        }
+        // corner lattice: three coordinates per axis (lattice_compat_oct / lattice_fpfh_oct)
+        int cx[3], cy[3], cz[3];
+#pragma unroll
+        for (int a = 0; a < 3; a++) {
+            cx[a] = min(max(cell_of(X + sh.lat[a][0], T.xMin, T.scale), 0), S - 1);
+            cy[a] = min(max(cell_of(Y + sh.lat[3 * a][1], T.yMin, T.scale), 0), S - 1);
+            cz[a] = min(max(cell_of(Z + sh.lat[9 * a][2], T.zMin, T.scale), 0), S - 1);
+        }
+        // ---- all first-level gathers of the point
+        float v[TC]; unsigned cd[TC];
+        if (T.code) {
+#pragma unroll
+            for (int j = 0; j < TC; j++) cd[j] = T.code[idx[j]];
+        } else {
+#pragma unroll
+            for (int j = 0; j < TC; j++) v[j] = T.dist[idx[j]];
+        }
+        unsigned mk[27]; int oc[27];
+        if (T.use_compat) {
+#pragma unroll
+            for (int l = 0; l < 27; l++) mk[l] = T.cmask[(size_t)((cz[l / 9] * S + cy[(l / 3) % 3]) * S + cx[l % 3])];
+        }
+        if (T.use_fpfh) {
+#pragma unroll
+            for (int l = 0; l < 27; l++) oc[l] = T.occ[(size_t)((cz[l / 9] * S + cy[(l / 3) % 3]) * S + cx[l % 3])];
+        }
+        const unsigned cls = (unsigned)T.dcls[ic];
+        // ---- second level: decoded distances, table entries
+        if (T.code) {
+#pragma unroll
+            for (int j = 0; j < TC; j++) v[j] = dt_decode(T, idx[j], cd[j], nullptr);
+        }
+        float fe[27];
+        if (T.use_fpfh) {
+            const float* Erow = T.fpE + (size_t)ic * T.nOcc;
+#pragma unroll
+            for (int l = 0; l < 27; l++) fe[l] = Erow[max(oc[l], 0)];
+        }
+        if (__any((int)oob)) {
+#pragma unroll
+            for (int j = 0; j < TC; j++) {
+                // (extension length from the cell coordinates already at hand -- dt_index would redo the three double conversions)
+                if ((oob >> j) & 1u) v[j] = dt_finish(T, v[j], dt_ext_raw(rx[j & 1], ry[j >> 1 & 1], rz[j >> 2 & 1], S));
+            }
+        }
+        // ---- addends of the two bounds (sweep_tile, parity mode, untrimmed)
+        if (valid) {
+#pragma unroll
+            for (int j = 0; j < TC; j++) {
+                float d = pw[m] * v[j];
+                if (use_rho) d -= prho[m];
+                if (d < 0.f) d = 0.f;
+                const float e = d - sh.mtd[j];
+                tub[j * Nd + i] = sq ? d * d : (lin ? d : 0.f);
+                tlb[j * Nd + i] = e > 0.f ? (sq ? e * e : (lin ? e : 0.f)) : 0.f;
+            }
+        }
+        if (T.use_compat) {
+#pragma unroll
+            for (int l = 0; l < 27; l++) wc[l] += __popcll(__ballot(valid && ((mk[l] >> cls) & 1u) == 0u));
+        }
+        if (T.use_fpfh && valid) {
+#pragma unroll
+            for (int l = 0; l < 27; l++) fprows[(size_t)l * Nd + i] = oc[l] < 0 ? 1000000000.f : fe[l];
+        }
+    }
+    if (T.use_compat && lane == 0) {
+#pragma unroll
+        for (int l = 0; l < 27; l++) if (wc[l]) atomicAdd(&sh.cnt[l], wc[l]);
+    }
+    __syncthreads();
+    // ---- the sequential float sums: 16 bound chains on wave 0, 27 c-FPFH chains on wave 1, side by side
+    if (tid < 2 * TC) {
+        const float* tt = rbuf + tid * Nd;          // lanes 0-7: ub rows, lanes 8-15: lb rows
+        float acc = 0.f;
+        int i = 0;
+        for (; i + 16 <= Nd; i += 16) {
+            float t16[16];
+#pragma unroll
+            for (int q = 0; q < 16; q++) t16[q] = tt[i + q];
+#pragma unroll
+            for (int q = 0; q < 16; q++) acc += t16[q];
+        }
+        for (; i < Nd; i++) acc += tt[i];
+        if (tid < TC) sh.ub[tid] = acc; else sh.lb[tid - TC] = acc;
+    } else if (T.use_fpfh && tid >= 64 && tid < 64 + 27) {
+        const float* fr = fprows + (size_t)(tid - 64) * Nd;
+        float acc = 0.f;
+        int i = 0;
+        for (; i + 16 <= Nd; i += 16) {
+            float t16[16];
+#pragma unroll
+            for (int q = 0; q < 16; q++) t16[q] = fr[i + q];
+#pragma unroll
+            for (int q = 0; q < 16; q++) acc += t16[q];
+        }
+        for (; i < Nd; i++) acc += fr[i];
+        sh.fpv[tid - 64] = acc / (float)Nd;
+    }
+    __syncthreads();
+}
+
+// ---------------------------------------------------------------------------------------------
+// binary heap with the element order of std::priority_queue<TRANSNODE> (reference jly_goicp.h:75-87):
+// the hole is sifted to a leaf along the not-lower child, then the displaced value is sifted up.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ bool node_lower(const HeapNode& p, const HeapNode& q) { return p.lb != q.lb ? p.lb > q.lb : p.w < q.w; }
+
+// node of the round-based search (k_fr_*): the queue entry plus the slot that holds its children's bounds once they are known
+struct __attribute__((aligned(16))) HeapNodeX { float x, y, z, w, ub, lb; int exp; int pad; };
+
+// storage: the first `hl` nodes live in LDS (the hot top of the heap), the rest in the job's global slab
+// Node moves go through explicit LDS / global address spaces: a plain `i < hl ? lds[i] : glb[i]` makes the compiler merge the two
+// pointers into a generic one and emit flat_load / flat_store, whose latency (and the double s_waitcnt they need) dominated the queue
+// work (k_fr_select: 10.8 k cycles per pop before, see profiles/).
+typedef unsigned qv4 __attribute__((ext_vector_type(4)));
+typedef unsigned qv2 __attribute__((ext_vector_type(2)));
+template <class N> struct NodeWords { typedef qv2 V; };
+template <> struct NodeWords<HeapNodeX> { typedef qv4 V; };
+template <class N>
+struct HeapStoreT {
+    N* lds; N* glb; int hl;
+    typedef typename NodeWords<N>::V V;
+    static constexpr int NV = sizeof(N) / sizeof(V);
+    union Pun { N n; V v[NV]; __device__ Pun() {} };
+    __device__ __forceinline__ N get(int i) const {
+        Pun u;
+        if (i < hl) {
+            const __attribute__((address_space(3))) V* q = (const __attribute__((address_space(3))) V*)(lds + i);
+#pragma unroll
+            for (int k = 0; k < NV; k++) u.v[k] = q[k];
+        } else {
+            const __attribute__((address_space(1))) V* q = (const __attribute__((address_space(1))) V*)(glb + i);
+#pragma unroll
+            for (int k = 0; k < NV; k++) u.v[k] = q[k];
+        }
+        return u.n;
+    }
+    __device__ __forceinline__ void set(int i, const N& v) const {
+        Pun u; u.n = v;
+        if (i < hl) {
+            __attribute__((address_space(3))) V* q = (__attribute__((address_space(3))) V*)(lds + i);
+#pragma unroll
+            for (int k = 0; k < NV; k++) q[k] = u.v[k];
+        } else {
+            __attribute__((address_space(1))) V* q = (__attribute__((address_space(1))) V*)(glb + i);
+#pragma unroll
+            for (int k = 0; k < NV; k++) q[k] = u.v[k];
+        }
+    }
+};
+typedef HeapStoreT<HeapNode> HeapStore;
+__device__ __forceinline__ bool key_lower(float plb, float pw, float qlb, float qw) { return plb != qlb ? plb > qlb : pw < qw; }
+struct HeapKey { float lb, w; };
+template <class N>
+__device__ __forceinline__ HeapKey heap_key(const HeapStoreT<N>& a, int i) {
+    HeapKey k;
+    if (i < a.hl) {
+        const __attribute__((address_space(3))) float* q = (const __attribute__((address_space(3))) float*)(a.lds + i);
+        k.w = q[3]; k.lb = q[5];
+    } else {
+        const __attribute__((address_space(1))) float* q = (const __attribute__((address_space(1))) float*)(a.glb + i);
+        k.w = q[3]; k.lb = q[5];
+    }
+    return k;
+}
+template <class N>
+__device__ __forceinline__ void heap_up(const HeapStoreT<N>& a, int hole, const N& v) {
+    int par = (hole - 1) / 2;
+    while (hole > 0) {
+        const HeapKey pk = heap_key(a, par);                      // compare on (lb, w) only; move whole nodes only when needed
+        if (!key_lower(pk.lb, pk.w, v.lb, v.w)) break;
+        a.set(hole, a.get(par)); hole = par; par = (hole - 1) / 2;
+    }
+    a.set(hole, v);
+}
+// heap_up for a whole wave (uniform hole and v): the ancestors of the hole are known up front, so lane k fetches ancestor k,
+// one ballot tells how many of them v passes (the leading run of "ancestor is lower"), those ancestors drop one slot down
+// the path in parallel and v lands above them -- the arrangement std::push_heap's loop produces, in one round trip to
+// the queue instead of one per level.
+template <class N>
+__device__ __forceinline__ void heap_up_wave(const HeapStoreT<N>& a, int hole, const N& v, int lane) {
+    const int depth = 31 - __clz(hole + 1);                      // ancestors: ((hole+1) >> (k+1)) - 1, k = 0 .. depth-1
+    const bool act = lane < depth;
+    N nk = v; bool rises = false;
+    if (act) { nk = a.get(((hole + 1) >> (lane + 1)) - 1); rises = key_lower(nk.lb, nk.w, v.lb, v.w); }
+    const unsigned long long up = __ballot(rises);
+    const int m = min(depth, __ffsll((long long)~up) - 1);       // lanes >= depth never rise, so ~up is never 0
+    wave_sync_lds();
+    if (lane < m) a.set(((hole + 1) >> lane) - 1, nk);            // ancestor k drops into the slot below it on the path
+    if (lane == 0) a.set(((hole + 1) >> m) - 1, v);
+    wave_sync_lds();
+}
+template <class N>
+__device__ __forceinline__ void heap_pop(const HeapStoreT<N>& a, int& n) {
+    if (n > 1) {
+        const int len = n - 1;
+        const N v = a.get(len);
+        a.set(len, a.get(0));
+        int hole = 0, child = 0;
+        while (child < (len - 1) / 2) {
+            child = 2 * (child + 1);
+            const HeapKey k1 = heap_key(a, child), k0 = heap_key(a, child - 1);
+            if (key_lower(k1.lb, k1.w, k0.lb, k0.w)) child--;
+            a.set(hole, a.get(child)); hole = child;
+        }
+        if ((len & 1) == 0 && child == (len - 2) / 2) { child = 2 * (child + 1); a.set(hole, a.get(child - 1)); hole = child - 1; }
+        heap_up(a, hole, v);
+    }
+    n--;
+}
+
+// heap_pop for a whole wave (uniform n): every lane walks the same path with broadcast reads, both children of a level are
+// fetched whole in one round trip (the chosen one moves up without a second read), lane 0 does the stores, and the displaced
+// last element rises with heap_up_wave. Same arrangement as heap_pop / std::pop_heap.
+template <class N>
+__device__ __forceinline__ void heap_pop_wave(const HeapStoreT<N>& a, int& n, int lane) {
+    if (n > 1) {
+        const int len = n - 1;
+        const N v = a.get(len);
+        const N top = a.get(0);
+        // the walk down only READS (the next level's children do not depend on this level's move); lane k remembers the node that
+        // moves up at level k and all moves are stored together afterwards -- one LDS round trip per level instead of a read-write pair
+        N mine = v; int mine_to = -1;
+        int hole = 0, child = 0, lvl = 0;
+        while (child < (len - 1) / 2) {
+            child = 2 * (child + 1);
+            const N c1 = a.get(child), c0 = a.get(child - 1);
+            const bool left = key_lower(c1.lb, c1.w, c0.lb, c0.w);
+            if (left) child--;
+            if (lane == lvl) { mine = left ? c0 : c1; mine_to = hole; }
+            hole = child; lvl++;
+        }
+        if ((len & 1) == 0 && child == (len - 2) / 2) {
+            child = 2 * (child + 1);
+            const N c0 = a.get(child - 1);
+            if (lane == lvl) { mine = c0; mine_to = hole; }
+            hole = child - 1; lvl++;
+        }
+        if (mine_to >= 0) a.set(mine_to, mine);
+        if (lane == 63) a.set(len, top);
+        wave_sync_lds();
+        heap_up_wave(a, hole, v, lane);
+    }
+    n--;
+}
+
+// ---------------------------------------------------------------------------------------------
+// sweep_stream: the tile sweep for clouds that do not fit a workgroup's registers (Nd > 8192; geometric error only, fp64 sums).
+// The workgroup walks the rotated cloud in chunks of 1024 points (coalesced float4 reads), 8 gathers per lane and chunk.
+// Untrimmed runs accumulate the two sums on the fly. Trimmed runs park the residuals in a per-workgroup row buffer in HBM
+// (8 x Nd floats; 288 GB make that affordable) and find the exact inlier threshold with the same histogram select as
+// sweep_tile: one pass over the rows for the 1024-bin window, one pass that sums everything below the threshold bin and
+// collects the bin's members, in-wave bisection of the low 16 bits; the generic byte passes re-read the rows.
+// ---------------------------------------------------------------------------------------------
+// PARTIAL = true (untrimmed runs only): the workgroup sweeps the points [p0, p1) of the cloud and leaves its 16 fp64 partial sums
+// (ub, lb per cube) in part_out instead of finishing the bounds -- one node's sweep split over several workgroups (k_fr_expand).
+template <bool OCT, int BLOCK = 1024, bool PARTIAL = false>
+__device__ __forceinline__ void sweep_stream(const DevTables& T, TileShm<BLOCK>& sh, const float4* __restrict__ rot, const float* __restrict__ rho_row,
+                                             float* __restrict__ rows, int NdP, int p0 = 0, int p1 = 0, double* __restrict__ part_out = nullptr,
+                                             const float* __restrict__ dual_rho = nullptr /* untrimmed, !PARTIAL: second call's radius row (see sweep_tile DUAL) */) {
+    const int tid = threadIdx.x, wv = tid >> 6, ln = tid & 63;
+    const int Nd = PARTIAL ? p1 : T.Nd, S = T.S;
+    const bool row_mode = !OCT && sh.ctl[2];
+    const bool sq = T.norm == 2, lin = T.norm == 1;
+    const bool trim = !PARTIAL && T.doTrim != 0;
+    if (!PARTIAL && T.exact_stream) {
+        // parity_mode 2 on a streamed cloud: the addend rows (untrimmed: 8 ub + 8 lb rows) or the residual rows (trimmed: 8 rows + 8 rows of
+        // selection scratch) of the tile go to this workgroup's [2 * TC][NdP] rows in HBM; then the reference-order arithmetic of sweep_tile's
+        // parity branches runs on them: one wave per cube for intro_select, 16 lanes for the 16 sequential float sums (jly_goicp.cpp:384-415).
+        constexpr int PB = BLOCK / 8, U = 8;
+        const int j = tid & 7, q = tid >> 3;
+        const float cx = sh.cen[j][0], cy = sh.cen[j][1], cz = sh.cen[j][2], mtd = sh.mtd[j];
+        for (int b = 0; b < Nd; b += PB * U) {
+            unsigned idx[U]; float w[U], rh[U], ext[U]; bool valid[U];
+#pragma unroll
+            for (int k = 0; k < U; k++) {
+                const int i = b + q + k * PB;
+                valid[k] = i < Nd;
+                const float4 p = rot[min(i, Nd - 1)];
+                rh[k] = rho_row ? rho_row[min(i, Nd - 1)] : 0.f;
+                const int x = cell_of(p.x + cx, T.xMin, T.scale), y = cell_of(p.y + cy, T.yMin, T.scale), z = cell_of(p.z + cz, T.zMin, T.scale);
+                idx[k] = (unsigned)((clamp_cell(z, S) * S + clamp_cell(y, S)) * S + clamp_cell(x, S));
+                ext[k] = dt_ext_raw(x, y, z, S);
+                w[k] = p.w;
+            }
+            float v[U];
+            if (T.code) {
+                unsigned c[U];
+#pragma unroll
+                for (int k = 0; k < U; k++) c[k] = T.code[idx[k]];
+#pragma unroll
+                for (int k = 0; k < U; k++) v[k] = dt_decode(T, idx[k], c[k], nullptr);
+            } else {
+#pragma unroll
+                for (int k = 0; k < U; k++) v[k] = T.dist[idx[k]];
+            }
+#pragma unroll
+            for (int k = 0; k < U; k++) {
+                float d = w[k] * dt_finish(T, v[k], ext[k]);
+                if (rho_row) d -= rh[k];
+                if (d < 0.f) d = 0.f;
+                const int i = b + q + k * PB;
+                if (valid[k]) {
+                    if (trim) rows[(size_t)j * NdP + i] = d;
+                    else {
+                        const float e = d - mtd;
+                        rows[(size_t)j * NdP + i] = sq ? d * d : (lin ? d : 0.f);
+                        rows[(size_t)(TC + j) * NdP + i] = e > 0.f ? (sq ? e * e : (lin ? e : 0.f)) : 0.f;
+                    }
+                }
+            }
+        }
+        __syncthreads();
+        if (trim) {
+            if (wv < TC) wave_intro_select<true>(rows + (size_t)wv * NdP, reinterpret_cast<int*>(rows + (size_t)(TC + wv) * NdP), Nd, T.inlierNum - 1, ln);
+            __syncthreads();
+        }
+        if (tid < 2 * TC) {
+            const int cj = tid & (TC - 1);
+            const bool is_lb = tid >= TC;
+            const float* rr = trim ? rows + (size_t)cj * NdP : rows + (size_t)tid * NdP;
+            const float sub = (trim && is_lb) ? sh.mtd[cj] : 0.f;
+            const int cnt = trim ? T.inlierNum : Nd;
+            float acc = 0.f;
+            auto add = [&](float d) {
+                if (!trim) { acc += d; return; }                    // (addends formed above)
+                const float e = d - sub;                            // (d - 0 == d exactly for the ub chain)
+                float term = sq ? e * e : (lin ? e : 0.f);
+                if (is_lb && !(e > 0.f)) term = 0.f;
+                acc += term;
+            };
+            int i = 0;
+            for (; i + 32 <= cnt; i += 32) {                        // 32 reads in flight, then the 32 dependent adds
+                float t32[32];
+#pragma unroll
+                for (int k = 0; k < 32; k++) t32[k] = rr[i + k];
+#pragma unroll
+                for (int k = 0; k < 32; k++) add(t32[k]);
+            }
+            for (; i < cnt; i++) add(rr[i]);
+            if (is_lb) sh.lb[cj] = acc; else sh.ub[cj] = acc;
+        }
+        __syncthreads();
+        return;
+    }
+    if (!trim) {
+        // Untrimmed runs keep nothing per point, so the sweep runs with lane = (point, cube): lane l adds up cube l & 7 over the points
+        // (l >> 3) + BLOCK/8 * k. The 8 lanes of a point read cells of nearby grid rows / one row, i.e. 8-32 cache lines per wave instruction
+        // instead of 64 unrelated ones -- the vector L1 works through the lines of an instruction one by one (tools/gather_modes.py: the same
+        // lookups in 1.85 ms instead of 3.77 ms on the configs[2] tiles). Two fp64 accumulators per lane, 8 lookups in flight.
+        constexpr int PB = BLOCK / 8, U = 8;
+        const int j = tid & 7, q = tid >> 3;
+        const float cx = sh.cen[j][0], cy = sh.cen[j][1], cz = sh.cen[j][2], mtd = sh.mtd[j];
+        double su1 = 0.0, sl1 = 0.0, su2 = 0.0, sl2 = 0.0;        // (su2, sl2: the second call of a fused pair -- same lookups, radius dual_rho)
+        for (int b = (PARTIAL ? p0 : 0); b < Nd; b += PB * U) {
+            unsigned idx[U]; float w[U], rh[U], rh2[U], ext[U]; bool valid[U];
+#pragma unroll
+            for (int k = 0; k < U; k++) {
+                const int i = b + q + k * PB;
+                valid[k] = i < Nd;
+                const float4 p = rot[min(i, Nd - 1)];
+                rh[k] = rho_row ? rho_row[min(i, Nd - 1)] : 0.f;
+                rh2[k] = dual_rho ? dual_rho[min(i, Nd - 1)] : 0.f;
+                const int x = cell_of(p.x + cx, T.xMin, T.scale), y = cell_of(p.y + cy, T.yMin, T.scale), z = cell_of(p.z + cz, T.zMin, T.scale);
+                idx[k] = (unsigned)((clamp_cell(z, S) * S + clamp_cell(y, S)) * S + clamp_cell(x, S));
+                ext[k] = dt_ext_raw(x, y, z, S);
+                w[k] = p.w;
+            }
+            float v[U];
+            if (T.code) {
+                unsigned c[U];
+#pragma unroll
+                for (int k = 0; k < U; k++) c[k] = T.code[idx[k]];
+#pragma unroll
+                for (int k = 0; k < U; k++) v[k] = dt_decode(T, idx[k], c[k], nullptr);
+            } else {
+#pragma unroll
+                for (int k = 0; k < U; k++) v[k] = T.dist[idx[k]];
+            }
+#pragma unroll
+            for (int k = 0; k < U; k++) {
+                float d = w[k] * dt_finish(T, v[k], ext[k]);
+                if (rho_row) d -= rh[k];
+                if (d < 0.f) d = 0.f;
+                const float e = d - mtd;
+                const float tu = sq ? d * d : (lin ? d : 0.f);
+                const float tl = sq ? e * e : (lin ? e : 0.f);
+                if (valid[k]) { su1 += (double)tu; if (e > 0.f) sl1 += (double)tl; }
+                if (dual_rho) {                               // minDis -= maxRotDisL; clamp (reference jly_goicp.cpp:375-381) on the same product
+                    float d2 = d - rh2[k];
+                    if (d2 < 0.f) d2 = 0.f;
+                    const float e2 = d2 - mtd;
+                    const float tu2 = sq ? d2 * d2 : (lin ? d2 : 0.f);
+                    const float tl2 = sq ? e2 * e2 : (lin ? e2 : 0.f);
+                    if (valid[k]) { su2 += (double)tu2; if (e2 > 0.f) sl2 += (double)tl2; }
+                }
+            }
+        }
+        if (dual_rho) {
+            // first call of the pair -> sh.ub2 / sh.lb2 (one more trip through the per-wave partials)
+            su1 = cube_sum(su1); sl1 = cube_sum(sl1);
+            if (ln < TC) { sh.red[wv][2 * ln] = su1; sh.red[wv][2 * ln + 1] = sl1; }
+            __syncthreads();
+            if (tid < TC) {
+                double u = 0.0, l = 0.0;
+                for (int w2 = 0; w2 < BLOCK / 64; w2++) { u += sh.red[w2][2 * tid]; l += sh.red[w2][2 * tid + 1]; }
+                sh.ub2[tid] = (float)u; sh.lb2[tid] = (float)l;
+            }
+            __syncthreads();
+            su1 = su2; sl1 = sl2;
+        }
+        su1 = cube_sum(su1); sl1 = cube_sum(sl1);
+        if (ln < TC) { sh.red[wv][2 * ln] = su1; sh.red[wv][2 * ln + 1] = sl1; }
+        __syncthreads();
+        if (tid < TC) {
+            double u = 0.0, l = 0.0;
+            for (int w2 = 0; w2 < BLOCK / 64; w2++) { u += sh.red[w2][2 * tid]; l += sh.red[w2][2 * tid + 1]; }
+            if (PARTIAL) { part_out[2 * tid] = u; part_out[2 * tid + 1] = l; }
+            else { sh.ub[tid] = (float)u; sh.lb[tid] = (float)l; }
+        }
+        __syncthreads();
+        return;
+    }
+    double su[TC], sl[TC]; unsigned mx[TC];
+#pragma unroll
+    for (int j = 0; j < TC; j++) { su[j] = 0.0; sl[j] = 0.0; mx[j] = 0u; }
+    auto add_terms = [&](int j, float d) {           // the two addends of one residual (jly_goicp.cpp:393-415), into lane-local fp64
+        const float e = d - sh.mtd[j];
+        const float tu = sq ? d * d : (lin ? d : 0.f);
+        const float tl = sq ? e * e : (lin ? e : 0.f);
+        su[j] += (double)tu;
+        if (e > 0.f) sl[j] += (double)tl;
+    };
+    // (only trimmed, order-free runs get here.) Pass 0, lane = (point, cube) as in the untrimmed sweep above: the residual rows go to HBM, every
+    // lane keeps the largest residual of its cube (the window of the histogram pass that follows, which reads the rows back lane = point).
+    {
+        constexpr int PB = BLOCK / 8, U = 8;
+        const int j = tid & 7, q = tid >> 3;
+        const float cx = sh.cen[j][0], cy = sh.cen[j][1], cz = sh.cen[j][2];
+        unsigned mx1 = 0u;
+        for (int b = 0; b < Nd; b += PB * U) {
+            unsigned idx[U]; float w[U], rh[U], ext[U]; bool valid[U];
+#pragma unroll
+            for (int k = 0; k < U; k++) {
+                const int i = b + q + k * PB;
+                valid[k] = i < Nd;
+                const float4 p = rot[min(i, Nd - 1)];
+                rh[k] = rho_row ? rho_row[min(i, Nd - 1)] : 0.f;
+                const int x = cell_of(p.x + cx, T.xMin, T.scale), y = cell_of(p.y + cy, T.yMin, T.scale), z = cell_of(p.z + cz, T.zMin, T.scale);
+                idx[k] = (unsigned)((clamp_cell(z, S) * S + clamp_cell(y, S)) * S + clamp_cell(x, S));
+                ext[k] = dt_ext_raw(x, y, z, S);
+                w[k] = p.w;
+            }
+            float v[U];
+            if (T.code) {
+                unsigned c[U];
+#pragma unroll
+                for (int k = 0; k < U; k++) c[k] = T.code[idx[k]];
+#pragma unroll
+                for (int k = 0; k < U; k++) v[k] = dt_decode(T, idx[k], c[k], nullptr);
+            } else {
+#pragma unroll
+                for (int k = 0; k < U; k++) v[k] = T.dist[idx[k]];
+            }
+#pragma unroll
+            for (int k = 0; k < U; k++) {
+                float d = w[k] * dt_finish(T, v[k], ext[k]);
+                if (rho_row) d -= rh[k];
+                if (d < 0.f) d = 0.f;
+                if (valid[k]) { rows[(size_t)j * NdP + b + q + k * PB] = d; mx1 = max(mx1, __float_as_uint(d)); }
+            }
+        }
+#pragma unroll
+        for (int jj = 0; jj < TC; jj++) mx[jj] = jj == j ? mx1 : 0u;
+    }
+    unsigned thr[TC]; int below[TC];
+#pragma unroll
+    for (int j = 0; j < TC; j++) { thr[j] = 0xFFFFFFFFu; below[j] = 0; }
+    if (trim) {
+        for (int k = tid; k < TC * 1024; k += BLOCK) (&sh.hist[0][0])[k] = 0u;
+        if (tid < TC) { sh.prefix[tid] = 0u; sh.rem[tid] = T.inlierNum - 1; sh.maxb[tid] = 0u; sh.zc[tid] = 0; sh.ncand[tid] = 0; }
+        if (tid == 0) sh.fallback = 0;
+        __syncthreads();                                   // also orders the row stores before the row loads below
+#pragma unroll
+        for (int j = 0; j < TC; j++) {
+            unsigned m = mx[j];
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) m = max(m, (unsigned)__shfl_down((int)m, off, 64));
+            if (ln == 0) atomicMax(&sh.maxb[j], m);
+        }
+        __syncthreads();
+        // pass 1 over the rows: 1024-bin window below each cube's maximum, exact zeros counted with ballots
+        {
+            int base16[TC], z[TC];
+#pragma unroll
+            for (int j = 0; j < TC; j++) { base16[j] = max(0, (int)(sh.maxb[j] >> 16) - 1023); z[j] = 0; }
+            for (int b = 0; b < Nd; b += BLOCK) {
+                const int i = b + tid;
+                const bool valid = i < Nd;
+                unsigned bits[TC];
+#pragma unroll
+                for (int j = 0; j < TC; j++) bits[j] = valid ? __float_as_uint(rows[(size_t)j * NdP + i]) : 0u;
+#pragma unroll
+                for (int j = 0; j < TC; j++) {
+                    z[j] += __popcll(__ballot(valid && bits[j] == 0u));
+                    if (valid && bits[j] != 0u) atomicAdd(&sh.hist[j][max(0, (int)(bits[j] >> 16) - base16[j])], 1u);
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < TC; j++) if (ln == 0 && z[j]) atomicAdd(&sh.zc[j], z[j]);
+        }
+        __syncthreads();
+        for (int j = wv; j < TC; j += BLOCK / 64) {          // one wave scans the 1024 bins of a cube: 16 per lane
+            unsigned c[16]; int mine = 0;
+#pragma unroll
+            for (int q = 0; q < 16; q++) { c[q] = sh.hist[j][16 * ln + q]; mine += (int)c[q]; }
+            int incl = mine;
+#pragma unroll
+            for (int off = 1; off < 64; off <<= 1) { const int t = __shfl_up(incl, off, 64); if (ln >= off) incl += t; }
+            const int zc = sh.zc[j];
+            const int rank = sh.rem[j];
+            if (rank < zc) {                                  // the threshold is one of the zeros
+                if (ln == 0) { sh.prefix[j] = 0u; sh.rem[j] = rank; sh.ncand[j] = -1; }
+                continue;
+            }
+            const int rem = rank - zc;
+            const unsigned long long over = __ballot(incl > rem);
+            const int owner = over ? __ffsll((long long)over) - 1 : 63;
+            if (ln == owner) {
+                int rr = rem - (incl - mine);
+                int bq = 0;
+#pragma unroll
+                for (int q = 0; q < 15; q++) { if (bq == q && rr >= (int)c[q]) { rr -= (int)c[q]; bq = q + 1; } }
+                unsigned cb = c[0];
+#pragma unroll
+                for (int q = 1; q < 16; q++) if (bq == q) cb = c[q];
+                const int bin = 16 * ln + bq;
+                const int base16 = max(0, (int)(sh.maxb[j] >> 16) - 1023);
+                if ((bin == 0 && base16 > 0) || cb > CAND_CAP) sh.fallback = 1;
+                sh.prefix[j] = (unsigned)(base16 + bin) << 16;
+                sh.rem[j] = rr;
+            }
+        }
+        __syncthreads();
+        const bool generic = sh.fallback != 0;
+        if (!generic) {
+            // pass 2 over the rows: everything below the threshold bin is summed, the bin's members are collected
+            unsigned p16[TC]; bool known[TC];
+#pragma unroll
+            for (int j = 0; j < TC; j++) { p16[j] = sh.prefix[j] >> 16; known[j] = sh.ncand[j] < 0; }
+            for (int b = 0; b < Nd; b += BLOCK) {
+                const int i = b + tid;
+                if (i < Nd) {
+                    float d[TC];
+#pragma unroll
+                    for (int j = 0; j < TC; j++) d[j] = rows[(size_t)j * NdP + i];
+#pragma unroll
+                    for (int j = 0; j < TC; j++) {
+                        const unsigned bits = __float_as_uint(d[j]);
+                        if (bits == 0u) continue;               // zeros add nothing to either sum
+                        const unsigned b16 = bits >> 16;
+                        if (b16 < p16[j]) add_terms(j, d[j]);
+                        else if (b16 == p16[j] && !known[j]) { const int pos = atomicAdd(&sh.ncand[j], 1); if (pos < CAND_CAP) sh.cand[j][pos] = bits; }
+                    }
+                }
+            }
+            __syncthreads();
+            for (int j = wv; j < TC; j += BLOCK / 64) {
+                const int nc = sh.ncand[j];
+                if (nc < 0) continue;
+                const bool v0 = ln < nc, v1 = ln + 64 < nc;
+                const unsigned c0 = v0 ? sh.cand[j][ln] : 0u, c1 = v1 ? sh.cand[j][ln + 64] : 0u;
+                const int rem = sh.rem[j];
+                unsigned pre = sh.prefix[j];
+#pragma unroll
+                for (int bb = 15; bb >= 0; bb--) {
+                    const unsigned cnd = pre | (1u << bb);
+                    const int cnt = __popcll(__ballot(v0 && c0 < cnd)) + __popcll(__ballot(v1 && c1 < cnd));
+                    if (cnt <= rem) pre = cnd;
+                }
+                const int less = __popcll(__ballot(v0 && c0 < pre)) + __popcll(__ballot(v1 && c1 < pre));
+                if (ln == 0) { sh.prefix[j] = pre; sh.rem[j] = rem - less; }
+                // the bin members below the threshold join this wave's partial sums of cube j
+#pragma unroll
+                for (int jj = 0; jj < TC; jj++) {
+                    if (jj == j) {
+                        if (v0 && c0 < pre) add_terms(jj, __uint_as_float(c0));
+                        if (v1 && c1 < pre) add_terms(jj, __uint_as_float(c1));
+                    }
+                }
+            }
+            __syncthreads();
+        } else {
+            if (tid < TC) { sh.prefix[tid] = 0u; sh.rem[tid] = T.inlierNum - 1; }
+            for (int pass = 3; pass >= 0; pass--) {
+                __syncthreads();
+                for (int k = tid; k < TC * 256; k += BLOCK) sh.hist[k >> 8][k & 255] = 0u;
+                __syncthreads();
+                const unsigned himask = pass == 3 ? 0u : (0xFFFFFFFFu << (8 * (pass + 1)));
+                unsigned pf[TC];
+#pragma unroll
+                for (int j = 0; j < TC; j++) pf[j] = sh.prefix[j];
+                for (int b = 0; b < Nd; b += BLOCK) {
+                    const int i = b + tid;
+                    const bool valid = i < Nd;
+#pragma unroll
+                    for (int j = 0; j < TC; j++) {
+                        const unsigned bits = valid ? __float_as_uint(rows[(size_t)j * NdP + i]) : 0u;
+                        const bool take = valid && ((bits ^ pf[j]) & himask) == 0u;
+                        hist_add(sh.hist[j], (bits >> (8 * pass)) & 255u, take, ln);
+                    }
+                }
+                __syncthreads();
+                for (int j = wv; j < TC; j += BLOCK / 64) {
+                    const unsigned c0 = sh.hist[j][4 * ln], c1 = sh.hist[j][4 * ln + 1], c2 = sh.hist[j][4 * ln + 2], c3 = sh.hist[j][4 * ln + 3];
+                    const int mine = (int)(c0 + c1 + c2 + c3);
+                    int incl = mine;
+#pragma unroll
+                    for (int off = 1; off < 64; off <<= 1) { const int t = __shfl_up(incl, off, 64); if (ln >= off) incl += t; }
+                    const int rem = sh.rem[j];
+                    const unsigned long long over = __ballot(incl > rem);
+                    const int owner = over ? __ffsll((long long)over) - 1 : 63;
+                    if (ln == owner) {
+                        int rr = rem - (incl - mine);
+                        unsigned dgt = 4u * ln;
+                        if (rr >= (int)c0) { rr -= (int)c0; dgt++; if (rr >= (int)c1) { rr -= (int)c1; dgt++; if (rr >= (int)c2) { rr -= (int)c2; dgt++; } } }
+                        sh.prefix[j] |= dgt << (8 * pass);
+                        sh.rem[j] = rr;
+                    }
+                }
+            }
+            __syncthreads();
+            unsigned tj[TC];
+#pragma unroll
+            for (int j = 0; j < TC; j++) tj[j] = sh.prefix[j];
+            for (int b = 0; b < Nd; b += BLOCK) {
+                const int i = b + tid;
+                if (i < Nd) {
+#pragma unroll
+                    for (int j = 0; j < TC; j++) { const float d = rows[(size_t)j * NdP + i]; if (__float_as_uint(d) < tj[j]) add_terms(j, d); }
+                }
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < TC; j++) { thr[j] = sh.prefix[j]; below[j] = T.inlierNum - 1 - sh.rem[j]; }
+    }
+#pragma unroll
+    for (int j = 0; j < TC; j++) {
+        const double u = wave_sum(su[j]), l = wave_sum(sl[j]);
+        if (ln == 0) { sh.red[wv][2 * j] = u; sh.red[wv][2 * j + 1] = l; }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < TC; j++) {
+        if (tid == j) {
+            double u = 0.0, l = 0.0;
+            for (int w = 0; w < BLOCK / 64; w++) { u += sh.red[w][2 * j]; l += sh.red[w][2 * j + 1]; }
+            if (PARTIAL) { part_out[2 * j] = u; part_out[2 * j + 1] = l; }
+            else {
+                if (trim) {
+                    const float d = __uint_as_float(thr[j]);
+                    const float e = d - sh.mtd[j];
+                    const double n = (double)(T.inlierNum - below[j]);
+                    if (sq) { u += n * (double)(d * d); if (e > 0.f) l += n * (double)(e * e); }
+                    else if (lin) { u += n * (double)d; if (e > 0.f) l += n * (double)e; }
+                }
+                sh.ub[j] = (float)u; sh.lb[j] = (float)l;
+            }
+        }
+    }
+    __syncthreads();
+}
+
+
+// ---- records of the round-based search (k_fr.hip), shared with the engine handle ----
+struct __attribute__((aligned(16))) FrExp { float ub[TC], lb[TC]; int child_base; int pad[3]; };   // child_base: first of the 8 records of the children's own children, or -1
+struct FrItem { int job, eid, split, pad; float x, y, z, w; };
+struct FrState {
+    float optErrorT, bx, by, bz, bw;
+    int found, status, done;
+    unsigned pops, cubes, spec;
+    int hn, ne, pend0, pad0, pad1;
+};
+struct FrCtx {
+    const goicp_bnb_job* jobs; FrState* st; goicp_bnb_result* results;
+    HeapNodeX* heaps; int heap_cap;
+    FrExp* exps; int exp_cap;
+    FrItem* wl; int wl_cap; unsigned* wl_count;      // wl_count[round], zeroed per batch of rounds
+    unsigned* active;                                  // active[round] = searches still running after that round's select
+    double* parts; int nsplit;                         // [job][eid][split][16] partial sums (streamed untrimmed clouds), else null / 1
+    int ngroups;                                       // work items per node and point slice: 1 (all 8 children) or 2 (4 children each)
+    float4* srot; int NdP;                             // rotated clouds [job][NdP]
+    unsigned max_pops;
+    unsigned long long* dbg;                           // [8] cycle sums of the busiest-looking phases of k_fr_select (GOICP_DBG & 32), else null
+};
+#define FR_LDS_NODES 4095          // queue nodes staged in LDS by k_fr_select (32 B each: 128 KB)
+#define FR_SELECT_THREADS 256
+

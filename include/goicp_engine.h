@@ -171,9 +171,12 @@ int goicp_engine_stats(const goicp_engine* h, uint64_t* cube_evals, uint64_t* lo
 /* round-based searches (clouds above 1024 points, geometric error): select/expand rounds launched so far and cube evaluations
  * launched by them (>= the evaluations the replay consumed: the difference is speculation that was not needed); 0 otherwise */
 int goicp_engine_search_stats(const goicp_engine* h, uint64_t* rounds, uint64_t* cube_evals_launched);
-/* diagnosis: run ONLY the distance-grid gathers of the last goicp_engine_eval_cubes_multi_dev launch shape (same grid, clouds, cubes, cell
- * arithmetic; nothing kept) and report the kernel time -- the memory-system floor of the sweep's access pattern. scratch_dev: >= n/8 floats. */
+#ifdef GOICP_PROBES
+/* diagnosis build only (make PROBES=1; absent from the shipped library): run ONLY the distance-grid gathers of the last
+ * goicp_engine_eval_cubes_multi_dev launch shape (same grid, clouds, cubes, cell arithmetic; nothing kept) and report the kernel time --
+ * the memory-system floor of the sweep's access pattern. scratch_dev: >= n/8 floats. */
 int goicp_engine_debug_gather_probe(goicp_engine* h, const void* cubes_dev, int n, void* scratch_dev, int variant, float* ms_out);
+#endif
 /* 1 if the last goicp_engine_eval_cubes_multi_dev call evaluated its (rot_level -1, rot_level >= 0) group pairs of one slot from ONE pass of
  * gathers (fused sweep: OuterBnB's ub / lb calls of a rotation read the same DT cells, reference jly_goicp.cpp:768,861), else 0 */
 int goicp_engine_last_eval_fused(const goicp_engine* h);
