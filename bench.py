@@ -37,7 +37,8 @@ TRIM = 0.1
 N_ROT = 16
 PEAK_HBM_GBPS = 8000.0          # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
 TILE_CUBES = 8                  # cubes that share one register-resident copy of the cloud (TC in engine.hip)
-PMC_SUMMARY = os.path.join("profiles", "r02_summary.json")     # written by tools/profile_round.sh from rocprofv3 --pmc passes of this command
+PMC_SUMMARY = os.path.join("profiles", "r03_summary.json")     # written by tools/profile_round.sh from rocprofv3 --pmc passes of this command
+PMC_SUMMARY_STRESS = os.path.join("profiles", "r03_c5_summary.json")   # the same for the configs[4]-shaped launch (python bench.py --points 50000 --dt 500 --trim 0)
 
 
 def level_cubes():
@@ -56,6 +57,15 @@ def algorithmic_bytes_per_cube_eval(nd):
     return nd * 4 + 8 + nd * 20 / TILE_CUBES
 
 
+def issued_bytes_per_launch(nd, evals_per_launch, fused):
+    """Bytes one launch actually requests: per tile of 8 cubes the cloud once (16 B per point + 4 B radius where a radius row is read) and one
+    4-B DT value per point and cube -- once per PAIR of cube-evals when (rho = 0, rho) group pairs are evaluated from one pass of gathers."""
+    if not fused:
+        return algorithmic_bytes_per_cube_eval(nd) * evals_per_launch
+    pair_evals = evals_per_launch / 2
+    return (nd * 4 + 16 + nd * 20 / TILE_CUBES) * pair_evals
+
+
 def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -70,7 +80,9 @@ def parse_args():
     ap.add_argument("--cpu-workers", type=int, default=0, help="all-cores CPU baseline: worker processes (0 = min(host cpus, 32))")
     ap.add_argument("--cavity-rows", type=int, default=383, help="rows of the configs[3] batch (whole job, sharded over the ranks)")
     ap.add_argument("--cavity-threads", type=int, default=16, help="host threads (= concurrent registrations, one engine + stream each) per rank")
-    ap.add_argument("--overlap-pairs", type=int, default=4, help="configs[2]-shaped pairs registered with their DT builds overlapped on host threads")
+    ap.add_argument("--overlap-pairs", type=int, default=16, help="configs[2]-shaped pairs registered with their DT builds overlapped on host threads (a box gives one GPU 16 host cores)")
+    ap.add_argument("--no-stress", action="store_true", help="skip the configs[4]-shaped sweep leg (50 000 points, 500^3 grid, untrimmed)")
+    ap.add_argument("--stress-steps", type=int, default=10)
     return ap.parse_args()
 
 
@@ -179,6 +191,9 @@ def main():
     assert np.isfinite(checksum)
     kname = eng.eval_kernel_name()
     fused = eng.last_eval_fused()
+    # `frac` counts SURVEY 8(d)'s bytes for every cube-eval; a fused (rho = 0, rho) pair is served by ONE pass of gathers, so the bytes the
+    # kernel actually asks the memory system for are fewer: frac_issued prices only the gathers made (memory-system utilisation)
+    issued_per_launch = issued_bytes_per_launch(nd, evals_per_step, fused)
     # The launch group holds every rotation twice (rho = 0 and rho = maxRotDis[3], as OuterBnB's ub / lb calls do), and the engine
     # evaluates such pairs from ONE pass of gathers (k_eval_cubes_geo<.., true>). For transparency the same launch group is also timed
     # with the fusion switched off (a second engine on the same grid): reported beside the line, never as `value`.
@@ -237,6 +252,13 @@ def main():
     if not args.no_register and args.cavity_rows > 0:
         cav = cavity_batch(goicp_amd, args, rank, world, local, use_dist, dist, dev, torch)
 
+    # ---- BASELINE configs[4] shape: 50 000 points, 500^3 grid (beyond the Infinity Cache), untrimmed: the HBM-bound sweep -------
+    stress = None
+    default_shape_run = nd == N_POINTS and args.dt == DT_SIZE and abs(args.trim - TRIM) < 1e-9
+    if rank == 0 and default_shape_run and not args.no_stress:
+        g.clear()                                   # (the registration legs left no engine; free the metric engine's blocks if they did not run)
+        stress = stress_leg(goicp_amd, synth_pair, local, torch, dev, args.stress_steps)
+
     # ---- CPU baseline: the unmodified reference (oracle/_ref) replaying the same InnerBnB calls, bounded -------
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu:
@@ -270,18 +292,78 @@ def main():
             "config": {"workload": "%s: synthetic %d-pt shell cloud vs rotated+noised copy (10%% outliers), trimFraction=%.1f, %d^3 DT; "
                                    "step = 16 rotations x 2 rho-variants x 4680 cubes (octree levels 1-4)" % (label, nd, args.trim, args.dt),
                        "points": nd, "dt_size": args.dt, "trimFraction": args.trim, "cube_evals_per_step": evals_per_step, "parallelism": "pairs sharded, 1 rank per GPU"},
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": PEAK_HBM_GBPS, "unit": "GB/s", "frac": achieved / PEAK_HBM_GBPS, "traffic": traffic,
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": PEAK_HBM_GBPS, "unit": "GB/s", "frac": achieved / PEAK_HBM_GBPS,
+                         "frac_issued": issued_per_launch / (kern_ms * 1e-3) / 1e9 / PEAK_HBM_GBPS, "issued_bytes_per_launch": issued_per_launch, "traffic": traffic,
                          "traffic_source": traffic_source, "kernel": kname, "avg_launch_ms": kern_ms, "algorithmic_bytes_per_launch": bytes_per_launch,
                          "point_lookups_per_sec": value / world * nd,
                          "fused_group_pairs": fused, "unfused": unfused},
             "cpu_baseline": cpu,
             "registration": reg,
             "cavity_batch": cav,
+            "stress": stress,
         }
         print(json.dumps(line))
     if use_dist:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def stress_leg(goicp_amd, synth_pair, local, torch, dev, steps):
+    """BASELINE configs[4] shape through the same launch group (16 rotations x 2 rho-variants x 4 680 cubes = 149 760 cube-evals per launch):
+    50 000 points streamed from HBM per tile, 500^3 grid (250 MB coded + 500 MB float: beyond the 256 MB Infinity Cache), untrimmed. The grid is
+    built on the device (dt_mode=1, milliseconds) -- the host builder would take seconds and the sweep does not care which builder made the grid."""
+    nd, S = 50000, 500
+    P = synth_pair(nd, seed=20260101, theta_range=(2.2, 3.1))
+    cfg = goicp_amd.cfg_vector(MSEThresh=1e-5, trimFraction=0.0, regularization=0.0, regularizationFPFH=0.0, cfpfh=0, ponderation=0, norm=2, distTransSize=S)
+    g = goicp_amd.GoICP(cfg, device_id=local, dt_mode=1); g.set_clouds(P["t"], P["s"]); g.build_dt(); g.initialize()
+    eng = g.engine()
+    rng = np.random.default_rng(20260102)
+    for s_ in range(N_ROT):
+        aa = rng.normal(size=3); aa = aa / np.linalg.norm(aa) * rng.uniform(0, np.pi)
+        th = np.linalg.norm(aa); k = aa / th
+        K = np.array([[0, -k[2], k[1]], [k[2], 0, -k[0]], [-k[1], k[0], 0]])
+        eng.set_rotation(s_, (np.eye(3) + np.sin(th) * K + (1 - np.cos(th)) * K @ K).astype(np.float32))
+    cubes_h = level_cubes(); ncube = len(cubes_h)
+    cubes = torch.from_numpy(cubes_h).to(dev)
+    ub = torch.empty((N_ROT * 2, ncube), dtype=torch.float32, device=dev); lb = torch.empty_like(ub)
+    g_slots = np.repeat(np.arange(N_ROT, dtype=np.int32), 2); g_levels = np.tile(np.array([-1, 3], np.int32), N_ROT)
+    stream = torch.cuda.ExternalStream(eng.stream(), device=dev)
+    for _ in range(2):
+        eng.eval_cubes_multi_dev(g_slots, g_levels, cubes.data_ptr(), ncube, ub.data_ptr(), lb.data_ptr())
+    eng.synchronize(); torch.cuda.synchronize()
+    ev0 = torch.cuda.Event(enable_timing=True); ev1 = torch.cuda.Event(enable_timing=True)
+    with torch.cuda.stream(stream):
+        ev0.record(stream)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        eng.eval_cubes_multi_dev(g_slots, g_levels, cubes.data_ptr(), ncube, ub.data_ptr(), lb.data_ptr())
+    with torch.cuda.stream(stream):
+        ev1.record(stream)
+    eng.synchronize(); torch.cuda.synchronize()
+    wall = time.perf_counter() - t0
+    kern_ms = ev0.elapsed_time(ev1) / steps
+    evals = N_ROT * 2 * ncube
+    fused = eng.last_eval_fused(); kname = eng.eval_kernel_name()
+    bytes_per_launch = algorithmic_bytes_per_cube_eval(nd) * evals
+    issued = issued_bytes_per_launch(nd, evals, fused)
+    assert np.isfinite(float(ub.double().sum().item() + lb.double().sum().item()))
+    g.close()
+    traffic = None; src = None
+    pj = os.path.join(ROOT, PMC_SUMMARY_STRESS)
+    if os.path.exists(pj):
+        try:
+            traffic = json.load(open(pj)).get("hbm_bytes_per_launch_by_kernel", {}).get(kname)
+            if traffic is not None:
+                src = "%s (separate rocprofv3 --pmc passes of `python bench.py --points 50000 --dt 500 --trim 0` on this build; not measured by this run)" % PMC_SUMMARY_STRESS
+        except Exception:
+            traffic = None
+    return {"workload": "configs[4] shape: synthetic 50000-pt cloud (10% outliers), untrimmed, 500^3 DT built on the device; step = 16 rotations x 2 rho-variants x 4680 cubes",
+            "value": evals * steps / wall, "unit": "cube-evals/s", "steps": steps, "ms_per_step": wall / steps * 1e3, "cube_evals_per_step": evals,
+            "point_lookups_per_sec": evals * steps / wall * nd,
+            "roofline": {"bound": "hbm", "achieved": bytes_per_launch / (kern_ms * 1e-3) / 1e9, "peak": PEAK_HBM_GBPS, "unit": "GB/s",
+                         "frac": bytes_per_launch / (kern_ms * 1e-3) / 1e9 / PEAK_HBM_GBPS, "frac_issued": issued / (kern_ms * 1e-3) / 1e9 / PEAK_HBM_GBPS,
+                         "traffic": traffic, "traffic_source": src, "kernel": kname, "avg_launch_ms": kern_ms, "algorithmic_bytes_per_launch": bytes_per_launch,
+                         "issued_bytes_per_launch": issued, "fused_group_pairs": fused}}
 
 
 def overlapped_registrations(goicp_amd, synth_pair, cfg, nd, n_pairs, local, world, rank, use_dist, dist, dev, torch):

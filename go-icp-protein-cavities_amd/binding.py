@@ -5,7 +5,7 @@ import os
 import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libgoicp_hip.so")
+LIB_PATH = os.environ.get("GOICP_LIB") or os.path.join(HERE, "libgoicp_hip.so")      # GOICP_LIB: the diagnosis build (make -C csrc probe) for tools/
 
 GOICP_OK = 0
 STATUS = {0: "OK", 1: "ERR_ARG", 2: "ERR_NO_DEVICE", 3: "ERR_HIP", 4: "ERR_OVERFLOW", 5: "ERR_LIMIT"}
@@ -47,7 +47,7 @@ class _Desc(C.Structure):
 
 class BnbJob(C.Structure):
     _fields_ = [("R", C.c_float * 9), ("rot_level", C.c_int32), ("optError_in", C.c_float), ("SSEThresh", C.c_float),
-                ("init", C.c_float * 4), ("init_lb", C.c_float), ("max_pops", C.c_uint32)]
+                ("init", C.c_float * 4), ("init_lb", C.c_float), ("max_pops", C.c_uint32), ("flags", C.c_uint32)]
 
 
 class BnbResult(C.Structure):
@@ -181,7 +181,7 @@ class Engine:
             J[i].rot_level = int(j["level"]); J[i].optError_in = float(j["E"]); J[i].SSEThresh = float(j["sse"])
             for k in range(4):
                 J[i].init[k] = float(j["init"][k])
-            J[i].init_lb = float(j.get("init_lb", 0.0)); J[i].max_pops = int(j.get("max_pops", 0))
+            J[i].init_lb = float(j.get("init_lb", 0.0)); J[i].max_pops = int(j.get("max_pops", 0)); J[i].flags = int(j.get("flags", 0))
         rc = self.L.goicp_engine_inner_bnb_batch(self.h, J, n, Rr)
         if rc not in (4, 5):      # ERR_OVERFLOW / ERR_LIMIT are per-job outcomes reported in each result's status
             self._chk(rc, "inner_bnb_batch")
@@ -253,6 +253,12 @@ class GoICP:
         if self.h:
             self.L.goicp_free(self.h)
             self.h = None
+
+    def set_budget(self, wall_seconds=0.0, search_pops=0):
+        """Budgets for searches that cannot run to convergence (BASELINE configs[4]): register() then returns the best pose so far and
+        out["budget_hit"] is True. 0 = none."""
+        if self.L.goicp_set_budget(self.h, C.c_double(float(wall_seconds)), C.c_uint32(int(search_pops))) != GOICP_OK:
+            raise EngineError("set_budget")
 
     def set_config(self, cfgvec):
         v = np.ascontiguousarray(cfgvec, dtype=np.float64)
@@ -352,9 +358,11 @@ class GoICP:
         st = np.zeros(8, np.uint64); ms = C.c_double()
         self.L.goicp_get_stats(self.h, _ptr(st), C.byref(ms))
         keys = ["rot_pops", "inner_calls", "inner_launches", "inner_jobs_launched", "cube_evals", "trans_pops", "icp_calls", "icp_iters"]
+        s6 = np.zeros(6, np.uint64); self.L.goicp_get_search_stats(self.h, _ptr(s6))
+        search = dict(pops_launched=int(s6[0]), rounds=int(s6[1]), cube_evals_launched=int(s6[2]), slab_regrowths=int(s6[3]), seconds=float(s6[4]) * 1e-6)
         return dict(R=out[:9].reshape(3, 3).copy(), t=out[9:12].copy(), error=np.float32(out[12]), comp=int(out[13]), Nd=int(out[14]),
                     inlierNum=int(out[15]), trace=[(names[tags[i]], float(vals[i])) for i in range(min(n, 256))],
-                    stats=dict(zip(keys, [int(v) for v in st])), kernel_ms=ms.value)
+                    stats=dict(zip(keys, [int(v) for v in st])), kernel_ms=ms.value, search=search, budget_hit=bool(s6[5]))
 
 
 _RES_KEYS = ["error", "compat", "Nd", "seconds", "dt_seconds"]

@@ -602,7 +602,7 @@ extern "C" int goicp_engine_create(const goicp_engine_desc* d, goicp_engine** ou
     h->n_cubes = h->n_lookups = 0; h->kernel_ms = 0; h->max_pops = 200000000u;
     h->code_escapes = 0; h->last_fused = 0;
     h->fr_mode = 0; h->fr_st = nullptr; h->fr_heaps = nullptr; h->fr_exps = nullptr; h->fr_wl = nullptr; h->fr_cnt = nullptr; h->fr_parts = nullptr; h->fr_srot = nullptr; h->fr_results = nullptr;
-    h->fr_jobs = 0; h->fr_cap_nodes = 0; h->fr_cap_exps = 0; h->fr_wl_cap = 0; h->fr_rounds = 0; h->fr_spec_cubes = 0;
+    h->fr_jobs = 0; h->fr_cap_nodes = 0; h->fr_cap_exps = 0; h->fr_wl_cap = 0; h->fr_rounds = 0; h->fr_spec_cubes = 0; h->n_regrow = 0;
 #define CR(call) do { int rc_ = (call); if (rc_ != GOICP_OK) { std::string m = h->err; goicp_engine_destroy(h); fprintf(stderr, "goicp_engine_create: %s\n", m.c_str()); return rc_; } } while (0)
 #define CRH(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { fprintf(stderr, "goicp_engine_create: %s: %s\n", #call, hipGetErrorString(e_)); goicp_engine_destroy(h); return GOICP_ERR_NO_DEVICE; } } while (0)
     {   // experiment knob: how this process's host threads wait for the device (spin is the runtime's default with idle cores)
@@ -829,6 +829,8 @@ extern "C" int goicp_engine_search_stats(const goicp_engine* h, uint64_t* rounds
     return GOICP_OK;
 }
 
+extern "C" uint64_t goicp_engine_slab_regrowths(const goicp_engine* h) { return h ? h->n_regrow : 0; }
+
 extern "C" int goicp_engine_set_rotation(goicp_engine* h, int slot, const float* R9) {
     if (!h || !R9 || slot < 0 || slot >= h->nslots) return GOICP_ERR_ARG;
     HIPCHK(h, hipSetDevice(h->device));
@@ -872,7 +874,7 @@ extern "C" const char* goicp_engine_eval_kernel_name(goicp_engine* h) {
     if (!h) return "";
     char buf[96];
     const bool jit = h->jit_eval != 0;
-    if (h->streamed) snprintf(buf, sizeof buf, "k_eval_cubes_stream<%d>", h->T.Nd > 16384 ? 1024 : 512);
+    if (h->streamed) snprintf(buf, sizeof buf, "k_eval_cubes_stream<%d,%s>", h->T.Nd > 16384 ? 1024 : 512, (h->last_fused ? "true" : "false"));
     else if (jit) snprintf(buf, sizeof buf, "k_eval_cubes_geo<%d,%s,%s>", 2 * h->ppt, h->npairs > 0 ? "true" : "false", h->T.exact_big ? "true" : "false");   // (DUAL: the group table of the last multi-group call paired up; XBIG: parity_mode 2)
     else snprintf(buf, sizeof buf, "k_eval_cubes<%d,%d,8,false>", h->block, h->ppt);
     h->kernel_name = buf;
@@ -977,8 +979,8 @@ extern "C" int goicp_engine_inner_bnb_batch(goicp_engine* h, const goicp_bnb_job
             // a job whose queue outgrew its slab is re-run alone on a larger one (the search is deterministic); jobs that carry a
             // pop budget are speculative and are simply reported as overflowed
             int cap = h->fr_mode ? h->fr_heap_cap : h->heap_cap;
-            while (r.status == GOICP_ERR_OVERFLOW && jobs[off + j].max_pops == 0 && cap < (1 << 26)) {
-                cap *= 16;
+            while (r.status == GOICP_ERR_OVERFLOW && (jobs[off + j].max_pops == 0 || (jobs[off + j].flags & GOICP_JOB_REGROW)) && cap < (1 << 26)) {
+                cap *= 16; h->n_regrow++;
                 if (h->fr_mode) rc = run_fr(h, jobs + off + j, 1, &r, cap);
                 else {
                     rc = ensure_big_heap(h, cap);

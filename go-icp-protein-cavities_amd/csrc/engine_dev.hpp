@@ -480,7 +480,13 @@ struct TileShm {
 // DUAL = true (just-in-time, non-parity form): the tile is evaluated for TWO calls that share rotation and cubes -- the ub-call
 // (no rotation uncertainty) and an lb-call (radius row dual_rho) -- from ONE pass of gathers: results of the first in sh.ub2 / sh.lb2,
 // of the second in sh.ub / sh.lb. OuterBnB's two InnerBnB calls per child rotation (jly_goicp.cpp:768,861) read the same DT cells.
-template <int BLOCK, int PPT, bool OCT, int NT, bool JIT = false, bool DUAL = false, bool XBIG = false /* JIT kernels: the parity_mode 2 instantiation (rows in HBM) */>
+// XP = true (NT = 8, at most 8 waves, coded grid): the gathers of a point are issued TRANSPOSED. With lane = point every gather instruction
+// carries 64 unrelated cells (64 line look-ups, and a point's 8 look-ups -- 1-3 cache lines of one grid row for a tile of x-neighbours -- go
+// out as 8 separate requests of which the L1 merges only some: 4.4 L2 requests per point and tile measured for 2.1 lines touched). Here the 8
+// lanes of a group swap their cell indices through LDS (the wave's own 4 KB row of sh.hist, which finish() clears afterwards) so that
+// instruction k carries the 8 cells of point k of every group: 8 lanes share 1-3 lines, one request each. The codes travel back the same way.
+// Values, arithmetic and the residual registers are untouched (lane = point everywhere else).
+template <int BLOCK, int PPT, bool OCT, int NT, bool JIT = false, bool DUAL = false, bool XBIG = false /* JIT kernels: the parity_mode 2 instantiation (rows in HBM) */, bool XP = false>
 __device__ __forceinline__ void sweep_tile(const DevTables& T, TileShm<BLOCK>& sh, const float (&px)[PPT], const float (&py)[PPT],
                                            const float (&pz)[PPT], const float (&pw)[PPT], const float (&prho)[PPT], bool use_rho,
                                            float* rbuf /* LDS, exact mode only */, bool row_mode = false /* !OCT: the cubes share y and z */,
@@ -556,7 +562,31 @@ __device__ __forceinline__ void sweep_tile(const DevTables& T, TileShm<BLOCK>& s
         } else { X = px[m]; Y = py[m]; Z = pz[m]; W = pw[m]; RH = prho[m]; }
         unsigned idx[NT]; float v[NT];
         const unsigned oob = cells(X, Y, Z, idx);
-        if (T.code) {
+        if (XP && T.code) {
+            static_assert(!XP || (NT == 8 && BLOCK / 64 <= TC), "transposed gathers: 8-cube tiles, one hist row per wave");
+            typedef __attribute__((address_space(3))) unsigned lds_u32;
+            typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
+            typedef __attribute__((address_space(3))) u32x4_t lds_u128;
+            // group g = 8 lanes; its 8x8 block sits at g*72 dwords (rows of 8 dwords: 16-byte aligned for the lane = point side, and the
+            // transposed side -- lane (g, p) touches dword g*72 + k*8 + p -- spreads a half-wave over all 32 banks)
+            lds_u32* xs = (lds_u32*)&sh.hist[tid >> 6][0] + ((tid & 63) >> 3) * 72;
+            const int p8 = (tid & 7) * 8, pp = tid & 7;
+            { u32x4_t w0 = {idx[0], idx[1], idx[2], idx[3]}; *(lds_u128*)(xs + p8) = w0; }
+            { u32x4_t w1 = {idx[4], idx[5], idx[6], idx[7]}; *(lds_u128*)(xs + p8 + 4) = w1; }
+            wave_sync_lds();
+            unsigned t[NT], c[NT];
+#pragma unroll
+            for (int k = 0; k < NT; k++) t[k] = xs[k * 8 + pp];
+#pragma unroll
+            for (int k = 0; k < NT; k++) c[k] = T.code[t[k]];
+#pragma unroll
+            for (int k = 0; k < NT; k++) xs[k * 8 + pp] = c[k];
+            wave_sync_lds();
+            const u32x4_t ca = *(lds_u128*)(xs + p8), cb = *(lds_u128*)(xs + p8 + 4);
+            c[0] = ca.x; c[1] = ca.y; c[2] = ca.z; c[3] = ca.w; c[4] = cb.x; c[5] = cb.y; c[6] = cb.z; c[7] = cb.w;
+#pragma unroll
+            for (int j = 0; j < NT; j++) v[j] = dt_decode(T, idx[j], c[j], lut_lds);
+        } else if (T.code) {
             // coded grid: 2-byte gathers (half the cache lines of the float grid), then the value from the LUT
             unsigned c[NT];
 #pragma unroll
@@ -680,7 +710,10 @@ __device__ __forceinline__ void sweep_tile(const DevTables& T, TileShm<BLOCK>& s
         const int wv = tid >> 6, ln = tid & 63;
         constexpr int NW = BLOCK / 64;
         // Five workgroup barriers for the whole selection + sums. Everything initialised here is first used after barrier 1.
-        for (int k = tid; k < NT * 1024; k += BLOCK) (&sh.hist[0][0])[k] = 0u;
+        if (XP) {           // wave w clears row w: its own transposition scratch, which no other wave may touch before this wave is done with it
+            for (int k = ln; k < 1024; k += 64) sh.hist[wv][k] = 0u;
+            for (int j = NW + wv; j < NT; j += NW) for (int k = ln; k < 1024; k += 64) sh.hist[j][k] = 0u;
+        } else for (int k = tid; k < NT * 1024; k += BLOCK) (&sh.hist[0][0])[k] = 0u;
         if (tid < NT) { sh.prefix[tid] = 0u; sh.rem[tid] = T.inlierNum - 1; sh.zc[tid] = 0; sh.ncand[tid] = 0; }
         if (tid == 0) sh.fallback = 0;
         // (1) largest residual per cube (fixes the 8-octave window of the histogram): per-wave maxima by plain stores

@@ -35,7 +35,7 @@ struct goicp_engine {
     int fr_ppt, fr_block, fr_nsplit, fr_wgs, fr_heap_cap, fr_depth2;
     FrState* fr_st; HeapNodeX* fr_heaps; FrExp* fr_exps; FrItem* fr_wl; unsigned* fr_cnt; double* fr_parts; float4* fr_srot; goicp_bnb_result* fr_results;
     size_t fr_jobs, fr_cap_nodes, fr_cap_exps; int fr_wl_cap;
-    uint64_t fr_rounds, fr_spec_cubes;
+    uint64_t fr_rounds, fr_spec_cubes, n_regrow;
     unsigned max_pops;
     uint64_t n_cubes, n_lookups; double kernel_ms;
     std::string err, kernel_name;

@@ -78,6 +78,9 @@ struct RegisterStats {
     uint64_t rot_pops = 0, inner_calls = 0, inner_launches = 0, inner_jobs_launched = 0, cube_evals = 0, trans_pops = 0, icp_calls = 0, icp_iters = 0;
     double engine_kernel_ms = 0;
     uint64_t pops_launched = 0;   // queue pops of every launched job, consumed by the replay or not (speculation cost)
+    uint64_t search_rounds = 0, cube_evals_launched = 0;   // round-based searches (clouds above 1024 points): select/expand rounds, cube evaluations launched
+    uint64_t slab_regrowths = 0;  // searches re-run on a 16x larger queue slab
+    double seconds = 0;           // wall time of Register()
 };
 
 class GoICP {
@@ -122,6 +125,11 @@ public:
     int speculate = 128;           // 0: one InnerBnB per launch; 1: the <=16 calls of a rotation pop per launch; M>1: also those of the next M-1 queue nodes
     bool device_icp = true;       // untrimmed cavity-sized clouds: ICP3D::Run as one launch (goicp_engine_icp_loop); false: one launch per iteration
     uint32_t spec_pop_budget = 20000;   // queue-pop budget of a speculative job (re-run unbounded if it turns out to be needed)
+    // budgets for searches that cannot be run to convergence (BASELINE configs[4]: 50 000 points, MSEThresh 1e-5): Register() then returns the best
+    // pose found so far with budget_hit = true and status OK. 0 = none (the reference's behaviour).
+    double wall_budget_s = 0;     // checked before every rotation-queue pop
+    uint32_t search_pop_budget = 0;   // translation-queue pops allowed to ONE InnerBnB call
+    bool budget_hit = false;
     int verbose = 0;              // echo the reference's "Error*: ..." progress lines to stdout
     int status = GOICP_OK;        // last engine status
     std::string error_message;
@@ -146,7 +154,7 @@ public:
 
 private:
     goicp_engine* eng_ = nullptr;
-    double icp_ms_ = 0;
+    double icp_ms_ = 0, t_start_ms_ = 0;
     std::vector<float> normData_, minDis_;
     std::vector<int32_t> icp_id_data_, icp_id_model_, opt_id_data_, opt_id_model_;
     std::vector<double> icp_dis_;

@@ -193,6 +193,19 @@ int goicp_get_stats(goicp_handle* h, uint64_t* s, double* ms) {
     return GOICP_OK;
 }
 
+int goicp_get_search_stats(goicp_handle* h, uint64_t* s) {
+    if (!h || !s) return GOICP_ERR_ARG;
+    const RegisterStats& st = h->g.stats;
+    s[0] = st.pops_launched; s[1] = st.search_rounds; s[2] = st.cube_evals_launched; s[3] = st.slab_regrowths; s[4] = (uint64_t)(st.seconds * 1e6); s[5] = h->g.budget_hit ? 1 : 0;
+    return GOICP_OK;
+}
+int goicp_set_budget(goicp_handle* h, double wall_seconds, uint32_t search_pops) {
+    if (!h || !(wall_seconds >= 0)) return GOICP_ERR_ARG;
+    h->g.wall_budget_s = wall_seconds; h->g.search_pop_budget = search_pops;
+    return GOICP_OK;
+}
+int goicp_budget_hit(goicp_handle* h) { return h && h->g.budget_hit ? 1 : 0; }
+
 void goicp_record_jobs(goicp_handle* h, int on) { if (h) h->g.record_jobs = on; }
 int goicp_get_job_log(goicp_handle* h, goicp_bnb_job* jobs, goicp_bnb_result* results, int cap) {
     if (!h) return 0;

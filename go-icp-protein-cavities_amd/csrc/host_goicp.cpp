@@ -547,7 +547,7 @@ static goicp_bnb_job make_job(const float* R9, int level, float E, float sse, co
     std::memcpy(j.R, R9, sizeof j.R);
     j.rot_level = level; j.optError_in = E; j.SSEThresh = sse;
     j.init[0] = init.x; j.init[1] = init.y; j.init[2] = init.z; j.init[3] = init.w; j.init_lb = init.lb;
-    j.max_pops = 0;
+    j.max_pops = 0; j.flags = 0;
     return j;
 }
 
@@ -589,6 +589,8 @@ void expand_plan(const ROTNODE& par, PopPlan& pl) {
 }
 }  // namespace
 
+static double now_ms() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+
 // reference jly_goicp.cpp:582-876
 float GoICP::OuterBnB() {
     std::map<PlanKey, PopPlan> plan_cache;
@@ -626,6 +628,7 @@ float GoICP::OuterBnB() {
         queueRot.pop();
         stats.rot_pops++;
         if ((optError - par.lb) <= SSEThresh) break;
+        if (wall_budget_s > 0 && (now_ms() - t_start_ms_) * 1e-3 > wall_budget_s) { budget_hit = true; break; }
         // The 16 InnerBnB calls of a rotation pop (8 children x {ub, lb}) are pure functions of (child rotation, level,
         // incumbent), so they can be evaluated ahead of time: one launch carries the jobs of this pop AND of the next
         // `speculate`-1 nodes at the head of the rotation queue. Results are cached per node and consumed strictly in the
@@ -645,6 +648,7 @@ float GoICP::OuterBnB() {
                 if (pl.have[k] && pl.res_E[k] == optError && pl.res[k].status == GOICP_OK) continue;
                 goicp_bnb_job jb = make_job(pl.Rj[j], (k & 1) ? pl.ch[j].l : -1, optError, SSEThresh, initNodeTrans);
                 if (spec || !jobs.empty()) jb.max_pops = spec_pop_budget;      // only the very first job is certain to be needed as is
+                else if (search_pop_budget) { jb.max_pops = search_pop_budget; jb.flags = GOICP_JOB_REGROW; }
                 jobs.push_back(jb); where.emplace_back(&pl, k);
                 if (speculate <= 0) break;
             }
@@ -686,6 +690,11 @@ float GoICP::OuterBnB() {
             if (!(plan.have[k] && plan.res_E[k] == optError && plan.res[k].status == GOICP_OK)) {
                 plan.have[k] = false;
                 if (!launch_from(k)) return nullptr;
+                if (plan.res[k].status == GOICP_ERR_LIMIT && search_pop_budget && plan.job[k].max_pops == search_pop_budget) {
+                    budget_hit = true;                   // this search is beyond the caller's budget: stop here with the best pose so far
+                    stats.trans_pops += plan.res[k].pops; stats.cube_evals += plan.res[k].cube_evals;
+                    return nullptr;
+                }
                 if (plan.res[k].status != GOICP_OK) {
                     status = plan.res[k].status;
                     char buf[160];
@@ -703,7 +712,7 @@ float GoICP::OuterBnB() {
             if (!live[j]) continue;
             ROTNODE& nodeRot = ch[j];
             const goicp_bnb_result* r = get(2 * j);
-            if (!r) return nanv;
+            if (!r) return budget_hit ? optError : nanv;
             ub = r->optErrorT;
             if (ub < optError) {
                 TRANSNODE nodeTrans = optNodeTrans;
@@ -732,7 +741,7 @@ float GoICP::OuterBnB() {
                 plan_cache.clear();          // every cached result was computed with the old incumbent
             }
             r = get(2 * j + 1);
-            if (!r) return nanv;
+            if (!r) return budget_hit ? optError : nanv;
             lb = r->optErrorT;
             if (lb >= optError) continue;
             nodeRot.ub = ub; nodeRot.lb = lb;
@@ -742,12 +751,11 @@ float GoICP::OuterBnB() {
     return optError;
 }
 
-static double now_ms() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
-
 float GoICP::Register() {
     trace.clear(); stats = RegisterStats(); job_log.clear(); result_log.clear(); icp_ms_ = 0;
     const bool timing = getenv("GOICP_TIMING") != nullptr;
     const double t0 = now_ms();
+    t_start_ms_ = t0; budget_hit = false;
     // non-finite coordinates would walk the (reference-order) selection and sorting loops out of their arrays: refuse them
     for (int i = 0; i < Nd; i++) if (!std::isfinite(pData[i].x) || !std::isfinite(pData[i].y) || !std::isfinite(pData[i].z)) {
         status = GOICP_ERR_ARG; error_message = "data cloud holds a non-finite coordinate"; return std::numeric_limits<float>::quiet_NaN();
@@ -772,6 +780,9 @@ float GoICP::Register() {
     double ms = 0; uint64_t ce = 0, lk = 0;
     goicp_engine_stats(eng_, &ce, &lk, &ms);
     stats.engine_kernel_ms = ms;
+    goicp_engine_search_stats(eng_, &stats.search_rounds, &stats.cube_evals_launched);
+    stats.slab_regrowths = goicp_engine_slab_regrowths(eng_);
+    stats.seconds = (now_ms() - t0) * 1e-3;
     Clear();
     if (status != GOICP_OK) return std::numeric_limits<float>::quiet_NaN();
     return optError;

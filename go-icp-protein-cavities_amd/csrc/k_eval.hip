@@ -5,7 +5,9 @@
 // k_eval_cubes_stream: k_eval_cubes for clouds above 8192 points. Persistent workgroups walk the (tile, group) list so
 // that the residual-row scratch (trimmed runs) is per resident workgroup, not per tile.
 // ---------------------------------------------------------------------------------------------
-template <int BLOCK>
+// DUAL (a template tag so that profilers list the fused and the plain launches as different kernels): `pairs` holds fused (no radius, radius)
+// group pairs as in k_eval_cubes_geo.
+template <int BLOCK, bool DUAL>
 __global__ __launch_bounds__(BLOCK, (BLOCK == 512 ? 4 : 1)) void k_eval_cubes_stream(DevTables T, const float4* __restrict__ rot_all, int slot0, int level0,
                                                             const int2* __restrict__ groups, int ngroups, const float* __restrict__ cubes, int n,
                                                             float* __restrict__ ub_out, float* __restrict__ lb_out,
@@ -19,7 +21,7 @@ __global__ __launch_bounds__(BLOCK, (BLOCK == 512 ? 4 : 1)) void k_eval_cubes_st
     for (long long w = blockIdx.x; w < total; w += gridDim.x) {
         const int g = (int)(w / tiles), base = (int)(w % tiles) * TC;
         int slot = slot0, rot_level = level0, row_a = g, row_b = g;
-        if (pairs) { const int4 pp = pairs[g]; slot = pp.x; rot_level = pp.y; row_a = pp.z; row_b = pp.w; }
+        if (DUAL) { const int4 pp = pairs[g]; slot = pp.x; rot_level = pp.y; row_a = pp.z; row_b = pp.w; }
         else if (groups) { const int2 gg = groups[g]; slot = gg.x; rot_level = gg.y; }
         if (tid < TC) {
             const int j = tid, c = min(base + j, n - 1);
@@ -35,7 +37,7 @@ __global__ __launch_bounds__(BLOCK, (BLOCK == 512 ? 4 : 1)) void k_eval_cubes_st
             sh.ctl[2] = row ? 1 : 0;
         }
         __syncthreads();
-        if (pairs) {
+        if (DUAL) {
             sweep_stream<false, BLOCK>(T, sh, rot_all + (size_t)slot * Nd, nullptr, rows, T.NdP, 0, 0, nullptr, T.maxRotDis + (size_t)rot_level * Nd);
             if (tid < TC && base + tid < n) {
                 ub_out[(size_t)row_a * n + base + tid] = sh.ub2[tid]; lb_out[(size_t)row_a * n + base + tid] = sh.lb2[tid];
@@ -245,7 +247,7 @@ __global__ __launch_bounds__(512, 4) void k_eval_cubes_geo(DevTables T, const fl
 #pragma unroll
     for (int m = 0; m < PPT; m++) { px[m] = py[m] = pz[m] = pw[m] = prho[m] = 0.f; }
     if constexpr (DUAL) {
-        sweep_tile<512, PPT, false, TC, true, true, XBIG>(T, sh, px, py, pz, pw, prho, false, xr, row, rot, nullptr, T.code ? lutl : nullptr, rho);
+        sweep_tile<512, PPT, false, TC, true, true, XBIG, !XBIG>(T, sh, px, py, pz, pw, prho, false, xr, row, rot, nullptr, T.code ? lutl : nullptr, rho);
         // (results out by lane id, from every wave alike -- identical values to identical addresses: the workitem id would have to survive the
         // whole sweep in a register the kernel does not have, i.e. in scratch)
         const int ol = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
@@ -254,7 +256,7 @@ __global__ __launch_bounds__(512, 4) void k_eval_cubes_geo(DevTables T, const fl
             ub_out[(size_t)g.w * n + base + ol] = sh.ub[ol];  lb_out[(size_t)g.w * n + base + ol] = sh.lb[ol];
         }
     } else {
-        sweep_tile<512, PPT, false, TC, true, false, XBIG>(T, sh, px, py, pz, pw, prho, g.y >= 0, xr, row, rot, rho, T.code ? lutl : nullptr);
+        sweep_tile<512, PPT, false, TC, true, false, XBIG, !XBIG>(T, sh, px, py, pz, pw, prho, g.y >= 0, xr, row, rot, rho, T.code ? lutl : nullptr);
         const int ol = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
         if (ol < TC && base + ol < n) { ub_out[(size_t)by * n + base + ol] = sh.ub[ol]; lb_out[(size_t)by * n + base + ol] = sh.lb[ol]; }
     }
@@ -304,8 +306,10 @@ int launch_eval(goicp_engine* h, int slot, int rot_level, const int2* groups_dev
         if (rcs != GOICP_OK) return rcs;
         // two 512-lane workgroups per CU overlap gathering and selection (+12 % at 6 000 points); from 16 K points on the sweep is
         // bound by the row and grid traffic itself and the 1024-lane form is as fast or faster
-        if (h->T.Nd > 16384) hipLaunchKernelGGL(k_eval_cubes_stream<1024>, dim3(wgs), dim3(1024), 0, h->stream, h->T, h->d_rot, slot, rot_level, groups_dev, ng, (const float*)cubes_dev, n, (float*)ub_dev, (float*)lb_dev, ptab);
-        else hipLaunchKernelGGL(k_eval_cubes_stream<512>, dim3(wgs), dim3(512), 0, h->stream, h->T, h->d_rot, slot, rot_level, groups_dev, ng, (const float*)cubes_dev, n, (float*)ub_dev, (float*)lb_dev, ptab);
+#define CALLS(B, D) hipLaunchKernelGGL((k_eval_cubes_stream<B, D>), dim3(wgs), dim3(B), 0, h->stream, h->T, h->d_rot, slot, rot_level, groups_dev, ng, (const float*)cubes_dev, n, (float*)ub_dev, (float*)lb_dev, ptab)
+        if (h->T.Nd > 16384) { if (dual) CALLS(1024, true); else CALLS(1024, false); }
+        else { if (dual) CALLS(512, true); else CALLS(512, false); }
+#undef CALLS
         HIPCHK(h, hipGetLastError());
         h->n_cubes += (uint64_t)n * ngroups; h->n_lookups += (uint64_t)n * ngroups * h->T.Nd;
         return GOICP_OK;

@@ -23,6 +23,10 @@ int goicp_set_config(goicp_handle*, const double* cfg18);
 int goicp_read_config(goicp_handle*, const char* path);         /* config.txt syntax of reference ConfigMap.cpp:17-60 */
 int goicp_get_config(goicp_handle*, double* cfg18);
 int goicp_set_options(goicp_handle*, int device_id, int parity_mode, int speculate, int verbose);
+/* budgets for searches that cannot run to convergence (BASELINE configs[4]); 0 = none. Register() then returns the best pose so far,
+ * status OK, and goicp_budget_hit() = 1. wall_seconds is checked before every rotation-queue pop; search_pops bounds ONE InnerBnB call. */
+int goicp_set_budget(goicp_handle*, double wall_seconds, uint32_t search_pops);
+int goicp_budget_hit(goicp_handle*);
 int goicp_set_clouds(goicp_handle*, int Nm, const float* mxyz, const int32_t* mcol, const float* mfpfh,
                      int Nd, const float* dxyz, const int32_t* dcol, const float* dfpfh);
 int goicp_set_nd(goicp_handle*, int Nd);                        /* goicp.Nd = NdDownsampled, reference jly_main.cpp:114-117 */
@@ -64,6 +68,9 @@ const char* goicp_error_message(goicp_handle*);
 int goicp_get_trace(goicp_handle*, int32_t* tags, float* values, int cap);
 /* stats8: rot_pops, inner_calls, inner_launches, inner_jobs_launched, cube_evals, trans_pops, icp_calls, icp_iters */
 int goicp_get_stats(goicp_handle*, uint64_t* stats8, double* engine_kernel_ms);
+/* stats6: queue pops launched (consumed or not), search rounds, cube evaluations launched by round-based searches, queue-slab regrowths,
+ * wall microseconds of Register(), budget_hit */
+int goicp_get_search_stats(goicp_handle*, uint64_t* stats6);
 
 /* consumed InnerBnB jobs of the last goicp_register (enable with goicp_record_jobs(h,1) before it); returns count */
 void goicp_record_jobs(goicp_handle*, int on);

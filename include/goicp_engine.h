@@ -104,8 +104,12 @@ typedef struct goicp_bnb_job {
     float   SSEThresh;
     float   init[4];       /* initNodeTrans x,y,z,w */
     float   init_lb;       /* initNodeTrans.lb (0 in the reference) */
-    uint32_t max_pops;     /* 0: engine default; else stop with GOICP_ERR_LIMIT after this many queue pops (speculative jobs) */
+    uint32_t max_pops;     /* 0: engine default; else stop with GOICP_ERR_LIMIT after this many queue pops (speculative jobs, caller budgets) */
+    uint32_t flags;        /* GOICP_JOB_* */
 } goicp_bnb_job;
+/* a job that outgrows its queue slab is re-run alone on a 16x larger one when it carries no pop budget (max_pops == 0); a job WITH a budget is
+ * taken for speculative and simply reported as GOICP_ERR_OVERFLOW -- unless it asks for the re-run with this flag */
+#define GOICP_JOB_REGROW 1u
 
 typedef struct goicp_bnb_result {
     float    optErrorT;    /* return value of InnerBnB */
@@ -171,6 +175,8 @@ int goicp_engine_stats(const goicp_engine* h, uint64_t* cube_evals, uint64_t* lo
 /* round-based searches (clouds above 1024 points, geometric error): select/expand rounds launched so far and cube evaluations
  * launched by them (>= the evaluations the replay consumed: the difference is speculation that was not needed); 0 otherwise */
 int goicp_engine_search_stats(const goicp_engine* h, uint64_t* rounds, uint64_t* cube_evals_launched);
+/* searches (goicp_engine_inner_bnb*) that outgrew their queue slab and were re-run alone on a 16x larger one, since engine creation */
+uint64_t goicp_engine_slab_regrowths(const goicp_engine* h);
 #ifdef GOICP_PROBES
 /* diagnosis build only (make PROBES=1; absent from the shipped library): run ONLY the distance-grid gathers of the last
  * goicp_engine_eval_cubes_multi_dev launch shape (same grid, clouds, cubes, cell arithmetic; nothing kept) and report the kernel time --

@@ -1,4 +1,4 @@
-# needs the diagnosis build: make -C go-icp-protein-cavities_amd/csrc clean all PROBES=1
+# needs the diagnosis build: make -C go-icp-protein-cavities_amd/csrc probe; run with GOICP_LIB=go-icp-protein-cavities_amd/libgoicp_hip_probe.so
 import os, sys, ctypes as C
 sys.path.insert(0,'/root/repo'); sys.path.insert(0,'/root/repo/tests')
 os.environ["GOICP_DBG"] = os.environ.get("GOICP_DBG", "32")      # (160 = 32 + 128: phases with the fused pop evaluation switched off)

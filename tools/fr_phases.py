@@ -1,4 +1,4 @@
-"""[needs the diagnosis build: make -C go-icp-protein-cavities_amd/csrc clean all PROBES=1] Diagnosis (GPU box): where k_fr_select spends its cycles. Replays the InnerBnB jobs of a configs[2]-shaped registration as one
+"""[needs the diagnosis build: make -C go-icp-protein-cavities_amd/csrc probe; run with GOICP_LIB=go-icp-protein-cavities_amd/libgoicp_hip_probe.so] Diagnosis (GPU box): where k_fr_select spends its cycles. Replays the InnerBnB jobs of a configs[2]-shaped registration as one
 batch with GOICP_DBG=32 and prints the per-phase cycle sums. python tools/fr_phases.py [points] [dt] [trim]"""
 import os, sys, time, ctypes as C
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))

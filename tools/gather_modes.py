@@ -1,4 +1,4 @@
-"""[needs the diagnosis build: make -C go-icp-protein-cavities_amd/csrc clean all PROBES=1] Diagnosis (GPU box): what the memory system charges the metric kernel's gathers for, and the workgroup -> XCD map.
+"""[needs the diagnosis build: make -C go-icp-protein-cavities_amd/csrc probe; run with GOICP_LIB=go-icp-protein-cavities_amd/libgoicp_hip_probe.so] Diagnosis (GPU box): what the memory system charges the metric kernel's gathers for, and the workgroup -> XCD map.
 (a) goicp_engine_debug_gather_probe variants on the real tiles: all 8 lookups per point / only 2 of them (the misses) / 8 loads of ONE
 cell (1 line, 7 loads that find it requested) / 8 loads on 8 grid rows (8 lines);  (b) the metric launch under GOICP_XCD = 0, 1, 2.
 python tools/gather_modes.py"""

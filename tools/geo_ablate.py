@@ -1,4 +1,4 @@
-"""[needs the diagnosis build: make -C go-icp-protein-cavities_amd/csrc clean all PROBES=1] Diagnosis (GPU box): the metric launch under the GOICP_DBG ablations (1 = no inlier selection, 2 = gathers folded onto a 4 KB
+"""[needs the diagnosis build: make -C go-icp-protein-cavities_amd/csrc probe; run with GOICP_LIB=go-icp-protein-cavities_amd/libgoicp_hip_probe.so] Diagnosis (GPU box): the metric launch under the GOICP_DBG ablations (1 = no inlier selection, 2 = gathers folded onto a 4 KB
 window, 3 = both; results are wrong by construction, timing only), fused and unfused.  python tools/geo_ablate.py"""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))

@@ -1,4 +1,4 @@
-"""[needs the diagnosis build: make -C go-icp-protein-cavities_amd/csrc clean all PROBES=1] Diagnosis (GPU box): cycles per iteration of the device-resident ICP loop (k_icp_loop) by phase, on the shipped cavity pairs."""
+"""[needs the diagnosis build: make -C go-icp-protein-cavities_amd/csrc probe; run with GOICP_LIB=go-icp-protein-cavities_amd/libgoicp_hip_probe.so] Diagnosis (GPU box): cycles per iteration of the device-resident ICP loop (k_icp_loop) by phase, on the shipped cavity pairs."""
 import os, sys, ctypes as C
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))

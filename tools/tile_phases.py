@@ -1,4 +1,4 @@
-"""[needs the diagnosis build: make -C go-icp-protein-cavities_amd/csrc clean all PROBES=1] Diagnosis (GPU box): per-phase cycles of the metric kernel's tile sweep (GOICP_DBG=64 stamps in sweep_tile).
+"""[needs the diagnosis build: make -C go-icp-protein-cavities_amd/csrc probe; run with GOICP_LIB=go-icp-protein-cavities_amd/libgoicp_hip_probe.so] Diagnosis (GPU box): per-phase cycles of the metric kernel's tile sweep (GOICP_DBG=64 stamps in sweep_tile).
 Needs a library built with the stamps compiled in: make -C go-icp-protein-cavities_amd/csrc clean all STAMPS=1
 python tools/tile_phases.py"""
 import os, sys, ctypes as C
