@@ -402,13 +402,16 @@ def cavity_batch(goicp_amd, args, rank, world, local, use_dist, dist, dev, torch
     # untimed warm-up: the first rows through the same driver with the same number of registrations in flight (code objects of the search and ICP
     # kernels, pooled streams / pinned buffers / device blocks of 16 engines), as the metric leg has its warm-up launches
     warm = min(32, max(1, args.cavity_rows // world))
+    # host threads (= registrations in flight) per rank: the waits spin, so never more threads than this rank's share of the host cores
+    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    threads = max(1, min(args.cavity_threads, cores // max(1, world)))
     driver.run_batch(base, tsv, cfgp, os.path.join(base, "warm_r%d" % rank), driver.gpu_register_fn(base, device_id=local), rank=rank, world=world,
-                     threads=args.cavity_threads, limit=min(args.cavity_rows, warm * world), schedule="rr", rmsd=False)      # (disjoint rows per rank: the pipeline writes per-row files)
+                     threads=threads, limit=min(args.cavity_rows, warm * world), schedule="rr", rmsd=False)      # (disjoint rows per rank: the pipeline writes per-row files)
     if use_dist:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    recs, n_rows = driver.run_batch(base, tsv, cfgp, outd, driver.gpu_register_fn(base, device_id=local), rank=rank, world=world, threads=args.cavity_threads,
+    recs, n_rows = driver.run_batch(base, tsv, cfgp, outd, driver.gpu_register_fn(base, device_id=local), rank=rank, world=world, threads=threads,
                                     dist=dist if use_dist else None)
     t_local = time.perf_counter() - t0
     allr = driver.gather_records(recs, n_rows, dist=dist if use_dist else None, device=dev if use_dist else None)   # THE exchange: one all_gather (RCCL)
@@ -417,11 +420,24 @@ def cavity_batch(goicp_amd, args, rank, world, local, use_dist, dist, dev, torch
         tt = torch.tensor([t_cav], dtype=torch.float64, device=dev); dist.all_reduce(tt, op=dist.ReduceOp.MAX); t_cav = float(tt.item())
     rm = allr[:, 19]
     per_rank = [int((allr[:, 21] == r).sum()) for r in range(world)]
+    weak = None
+    if world > 1:
+        # weak-scaling leg: EVERY rank registers the whole batch on files of its own (the strong leg above is bounded by the longest pair once
+        # the rows are spread over 8 GPUs); no exchange, max over ranks
+        wbase = base + "_weak_r%d" % rank
+        wtsv, wcfg, _ = c4_batch.materialise(wbase, os.path.join(ROOT, "tests", "golden", "data"), rows=args.cavity_rows)
+        dist.barrier(); torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        wrecs, _ = driver.run_batch(wbase, wtsv, wcfg, os.path.join(wbase, "output"), driver.gpu_register_fn(wbase, device_id=local), rank=0, world=1, threads=threads, rmsd=False)
+        tw = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=dev); dist.all_reduce(tw, op=dist.ReduceOp.MAX)
+        nw = torch.tensor([float(len(wrecs))], dtype=torch.float64, device=dev); dist.all_reduce(nw, op=dist.ReduceOp.SUM)
+        weak = dict(pairs=int(nw.item()), seconds=float(tw.item()), cavity_pair_registrations_per_sec=float(nw.item()) / float(tw.item()),
+                    scaling="weak (every rank registers all %d rows)" % args.cavity_rows)
     return dict(pairs=int(allr.shape[0]), seconds=t_cav, cavity_pair_registrations_per_sec=allr.shape[0] / t_cav, cube_evals=int(np.nansum(allr[:, 18])),
-                concurrent_registrations_per_gpu=args.cavity_threads, warmup_pairs=warm, scaling="strong (the whole batch is divided over the ranks)",
+                concurrent_registrations_per_gpu=threads, host_cores=cores, warmup_pairs=warm, scaling="strong (the whole batch is divided over the ranks)",
                 schedule="longest-first, rows drawn from one shared counter" if world > 1 else "longest-first", pairs_per_rank=per_rank,
                 failed=int((allr[:, 20] != 0).sum()), rmsd_gathered=int((~np.isnan(rm)).sum()), rmsd_median=float(np.nanmedian(rm)), rmsd_below_2A=int((rm < 2.0).sum()),
-                rank0_seconds_before_gather=t_local,
+                rank0_seconds_before_gather=t_local, weak=weak,
                 config="BASELINE configs[3]: rows 1-2 shipped cavity pairs, rows 3-%d seeded synthetic cavity-like pairs (N in [150,400]); shipped config.txt + cfpfh=1, regularizationFPFH=5e-6; file pipeline incl. protein transform + RMSD" % args.cavity_rows,
                 _base=base, _tsv=tsv, _cfg=cfgp)
 

@@ -75,12 +75,13 @@ __global__ void k_build_codes(const float* __restrict__ dist, const float* __res
 __global__ void k_rotate(DevTables T, const float* __restrict__ R, float4* __restrict__ out) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= T.Nd) return;
-    const float x = T.dxyz[3 * i], y = T.dxyz[3 * i + 1], z = T.dxyz[3 * i + 2];
+    const int s = T.perm ? T.perm[i] : i;
+    const float x = T.dxyz[3 * s], y = T.dxyz[3 * s + 1], z = T.dxyz[3 * s + 2];
     float4 p;
     p.x = R[0] * x + R[1] * y + R[2] * z;
     p.y = R[3] * x + R[4] * y + R[5] * z;
     p.z = R[6] * x + R[7] * y + R[8] * z;
-    p.w = T.weights[i];
+    p.w = T.weights[s];
     out[i] = p;
 }
 
@@ -640,6 +641,7 @@ extern "C" int goicp_engine_create(const goicp_engine_desc* d, goicp_engine** ou
     if (sparse) T.dist = (const float*)d->dt_dist_dev;        // adopted in place (owned by the caller's goicp_dtgpu handle)
     else { float* p_dist; CR(dev_upload(h, d->dt_dist, ncell, &p_dist)); T.dist = p_dist; }
     T.code = nullptr; T.lut = nullptr;
+    T.extq = nullptr; T.extq_n = 0;
     std::vector<float> lut;                     // (sources of deferred uploads live to the end of this function)
     std::vector<int> occ_cells, occ_ptr(1, 0), occ_pts;
     std::vector<uint16_t> occ_mask;
@@ -762,6 +764,21 @@ extern "C" int goicp_engine_create(const goicp_engine_desc* d, goicp_engine** ou
     { unsigned long long* p_t; CR(dev_upload<unsigned long long>(h, nullptr, 16, &p_t)); CRH(hipMemsetAsync(p_t, 0, 128, h->stream)); T.dbg_times = p_t; }
     pick_geometry(h);
     h->jit_eval = (h->block == 1024 && h->ppt >= 2 && !T.exact && !T.use_compat && !T.use_fpfh && !env_is_zero("GOICP_JIT")) ? 1 : 0;
+    T.perm = nullptr; T.maxRotDisP = nullptr;
+    std::vector<int> perm; std::vector<float> mrdP;
+    if (h->jit_eval && !T.exact_big && !env_is_zero("GOICP_SORT")) {
+        // metric kernel: the slot clouds are stored by decreasing norm. A look-up leaves the grid only for points far from the centre, and a wave
+        // pays for the out-of-grid extension (double-precision sqrt / divide) whenever ONE of its lanes needs it: with the far points next to each
+        // other few waves do. The sums of this path are order-free (fp64), the inlier selection is a multiset: results do not depend on the order.
+        perm.resize((size_t)d->Nd);
+        std::vector<float> nrm((size_t)d->Nd);
+        for (int i = 0; i < d->Nd; i++) { perm[(size_t)i] = i; const float* q = d->data_xyz + 3 * (size_t)i; nrm[(size_t)i] = q[0] * q[0] + q[1] * q[1] + q[2] * q[2]; }
+        std::stable_sort(perm.begin(), perm.end(), [&](int a, int b) { return nrm[(size_t)a] > nrm[(size_t)b]; });
+        mrdP.resize((size_t)GOICP_MAXROTLEVEL * d->Nd);
+        for (int l = 0; l < GOICP_MAXROTLEVEL; l++) for (int i = 0; i < d->Nd; i++) mrdP[(size_t)l * d->Nd + i] = d->maxRotDis[(size_t)l * d->Nd + perm[(size_t)i]];
+        int* p_perm; CR(dev_upload(h, perm.data(), perm.size(), &p_perm)); T.perm = p_perm;
+        float* p_mp; CR(dev_upload(h, mrdP.data(), mrdP.size(), &p_mp)); T.maxRotDisP = p_mp;
+    }
     if (h->dyn_lds_bnb + sizeof(TileShm<1024>) + 64 > 160 * 1024) { h->err = "LDS budget exceeded"; CR(GOICP_ERR_ARG); }
     {
         // static tile state + residual rows + LDS heap can exceed the 64 KB a launch gets without asking: each kernel family raises the

@@ -37,6 +37,7 @@ struct DevTables {
     // 2-byte coded copy of the grid (see k_build_codes): code = squared cell distance d2 when dist == lut[d2] bit for bit and d2 < 65535,
     // else 0xFFFF (the value is then read from `dist`). Twice the cells per cache line of the gather stream; null = not built.
     const uint16_t* code; const float* lut;
+    const double* extq; int extq_n;   // out-of-grid extension: (double)sqrtf((float)n) / scale for n = a*a + b*b + c*c < extq_n (jly_3ddt.cpp:1150-1190), tabulated on the host
     const uint16_t* cmask;
     const int* occ;          // [S^3] compact id of the nearest occupied cell, -1 if none
     const int* occ_ptr;      // [nOcc+1]
@@ -49,6 +50,8 @@ struct DevTables {
     const uint8_t* dcls;     // [Nd] colour class of each data point
     const float* weights;    // [Nd]
     const float* maxRotDis;  // [20*Nd]
+    const int* perm; const float* maxRotDisP;   // metric kernel (order-free sums): slot clouds hold point perm[i] at position i (far points first, so that the
+                                                // rare out-of-grid lanes share wave-iterations); maxRotDisP = the radius rows in that order. Null = identity.
     int Nd, Nm, inlierNum, doTrim, norm, b0, b1;
     float reg, regFPFH;
     int use_compat, use_fpfh, exact;
@@ -106,6 +109,12 @@ __device__ __forceinline__ float dt_ext_raw(int x, int y, int z, int S) {
 __device__ __forceinline__ float dt_finish(const DevTables& T, float v, float ext) {
     if (ext > 0.f) v = (float)((double)ext / T.scale + (double)v);      // float sqrt, double divide and add, rounded to float
     return v;
+}
+// the same from the integer squared extension length n = a*a + b*b + c*c (a, b, c: cells beyond the grid; the float products and sums of the
+// reference are exact for these small integers): sqrtf((float)n) / scale comes from a host-built table for small n, bit for bit the same quotient
+__device__ __forceinline__ float dt_finish_n(const DevTables& T, float v, int n) {
+    const double q = (double)sqrtf((float)n) / T.scale;      // (a host-built table of these quotients in global memory measured far slower: a dependent load per cube inside the gather loop)
+    return (float)(q + (double)v);
 }
 __device__ __forceinline__ float dt_lookup(const DevTables& T, float X, float Y, float Z) {
     float ext;
@@ -469,6 +478,7 @@ struct TileShm {
     int cnt[NLMAX];
     float fpv[NLMAX];
     int ctl[4];               // [0] done flag, [1] status
+    unsigned himask;          // fixed-window selection (XP): bit j = cube j has residuals above the window
 };
 
 // Evaluate the TC cubes whose descriptors sit in sh.cube[] against the PPT points each lane holds in
@@ -480,6 +490,26 @@ struct TileShm {
 // DUAL = true (just-in-time, non-parity form): the tile is evaluated for TWO calls that share rotation and cubes -- the ub-call
 // (no rotation uncertainty) and an lb-call (radius row dual_rho) -- from ONE pass of gathers: results of the first in sh.ub2 / sh.lb2,
 // of the second in sh.ub / sh.lb. OuterBnB's two InnerBnB calls per child rotation (jly_goicp.cpp:768,861) read the same DT cells.
+// ---- fixed-window selection of the metric kernel (sweep_tile<..., XP = true>) ----
+// The inlier threshold is found on a histogram of the residuals' bit patterns. With a FIXED window -- key = bits >> 17 (sign, exponent, 6 mantissa
+// bits) relative to 2^-12, i.e. 1024 bins over the 16 octaves [2^-12, 2^4) -- no pass for the per-cube maximum is needed, and the histogram of
+// the first selection is accumulated INSIDE the gather loop (LDS adds beside the outstanding gathers, nothing waits for them). Counters are 16 bits
+// (a cube has at most 8192 residuals), two bins per LDS word: the 8 histograms take the lower half of sh.hist, the transposition scratch of
+// the 8 waves the upper half. A threshold that falls outside the window or into a crowded bin takes the generic byte passes, as before.
+#define FW_SHIFT 17
+#define FW_KBASE ((int)(0x39800000u >> FW_SHIFT))        // key of 2^-12
+#define FW_HP_WORDS 512                                   // packed words per cube histogram
+template <int BLOCK>
+__device__ __forceinline__ void fw_hist_reset(TileShm<BLOCK>& sh) {   // every lane of the workgroup; a workgroup barrier must follow before the first add
+    typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
+    typedef __attribute__((address_space(3))) u32x4_t lds_u128;
+    lds_u128* hp = (lds_u128*)&sh.hist[0][0];
+    const u32x4_t z = {0u, 0u, 0u, 0u};
+    for (int k = threadIdx.x; k < TC * FW_HP_WORDS / 4; k += BLOCK) hp[k] = z;
+    if (threadIdx.x < TC) { sh.prefix[threadIdx.x] = 0u; sh.zc[threadIdx.x] = 0; sh.ncand[threadIdx.x] = 0; }
+    if (threadIdx.x == 0) { sh.fallback = 0; sh.himask = 0u; }
+}
+
 // XP = true (NT = 8, at most 8 waves, coded grid): the gathers of a point are issued TRANSPOSED. With lane = point every gather instruction
 // carries 64 unrelated cells (64 line look-ups, and a point's 8 look-ups -- 1-3 cache lines of one grid row for a tile of x-neighbours -- go
 // out as 8 separate requests of which the L1 merges only some: 4.4 L2 requests per point and tile measured for 2.1 lines touched). Here the 8
@@ -546,11 +576,36 @@ __device__ __forceinline__ void sweep_tile(const DevTables& T, TileShm<BLOCK>& s
 #ifdef GOICP_TILE_STAMPS
     const bool stamp = DBG_ON(T, 64) && T.dbg_times && tid == 0 && (blockIdx.x & 63) == 0;
     unsigned long long tl_ = stamp ? clock64() : 0ull;
+    const unsigned long long tw0_ = stamp ? wall_clock64() : 0ull;      // [8]: the same tile in 100 MHz wall ticks -> in-kernel clock = cycles / ticks x 100 MHz
 #define TSTAMP(k) do { if (stamp) { const unsigned long long now_ = clock64(); atomicAdd(&T.dbg_times[k], now_ - tl_); tl_ = now_; } } while (0)
 #else
     constexpr bool stamp = false;
 #define TSTAMP(k) do { } while (0)
 #endif
+    // fixed-window histogram adds (XP): zeros and out-of-window flags are wave-uniform counts (ballots), flushed once per wave
+    int fw_z[NT]; unsigned fw_hi = 0u;
+#pragma unroll
+    for (int j = 0; j < NT; j++) fw_z[j] = 0;
+    auto fw_add = [&](int j, float d, bool valid) __attribute__((always_inline)) {
+        typedef __attribute__((address_space(3))) unsigned lds_u32;
+        const unsigned bits = __float_as_uint(d);
+        const bool nz = valid && bits != 0u;
+        fw_z[j] += __popcll(__ballot(valid && bits == 0u));
+        int k = (int)(bits >> FW_SHIFT) - FW_KBASE;
+        fw_hi |= (__ballot(nz && k > 1023) ? 1u : 0u) << j;
+        k = min(max(k, 0), 1023);
+        if (nz) atomicAdd((unsigned*)((lds_u32*)&sh.hist[0][0] + j * FW_HP_WORDS + (k >> 1)), 1u << ((k & 1) * 16));
+    };
+    auto fw_flush = [&]() __attribute__((always_inline)) {
+        if ((tid & 63) == 0) {
+#pragma unroll
+            for (int j = 0; j < NT; j++) if (fw_z[j]) atomicAdd(&sh.zc[j], fw_z[j]);
+            if (fw_hi) atomicOr(&sh.himask, fw_hi);
+        }
+#pragma unroll
+        for (int j = 0; j < NT; j++) fw_z[j] = 0;
+        fw_hi = 0u;
+    };
     float4 pnext = make_float4(0.f, 0.f, 0.f, 0.f); float rnext = 0.f;
     if (JIT) { const int i0 = min(tid, Nd - 1); pnext = jit_rot[i0]; rnext = jit_rho ? jit_rho[i0] : 0.f; }
 #pragma unroll
@@ -562,48 +617,89 @@ __device__ __forceinline__ void sweep_tile(const DevTables& T, TileShm<BLOCK>& s
         } else { X = px[m]; Y = py[m]; Z = pz[m]; W = pw[m]; RH = prho[m]; }
         unsigned idx[NT]; float v[NT];
         const unsigned oob = cells(X, Y, Z, idx);
+        auto decode_all = [&](const unsigned (&c)[NT]) __attribute__((always_inline)) {
+#ifdef GOICP_DECODE2
+            // codes below LUT_LDS (within 90 cells of the model: nearly all) come from the LDS table without a branch per value; the rest --
+            // far cells through the global table, escapes through the float grid -- are patched under ONE wave-wide test
+            if (XP && lut_lds) {
+                typedef __attribute__((address_space(3))) float lds_f32;
+                const lds_f32* q = (const lds_f32*)lut_lds;
+                bool far = false;
+#pragma unroll
+                for (int j = 0; j < NT; j++) far = far || c[j] >= (unsigned)LUT_LDS;
+#pragma unroll
+                for (int j = 0; j < NT; j++) v[j] = q[min(c[j], (unsigned)(LUT_LDS - 1))];
+                if (__any(far ? 1 : 0)) {
+#pragma unroll
+                    for (int j = 0; j < NT; j++) if (c[j] >= (unsigned)LUT_LDS) v[j] = c[j] != 0xFFFFu ? T.lut[c[j]] : T.dist[idx[j]];
+                }
+                return;
+            }
+#endif
+#pragma unroll
+            for (int j = 0; j < NT; j++) v[j] = dt_decode(T, idx[j], c[j], lut_lds);
+        };
+#ifndef GOICP_NO_XP
         if (XP && T.code) {
             static_assert(!XP || (NT == 8 && BLOCK / 64 <= TC), "transposed gathers: 8-cube tiles, one hist row per wave");
             typedef __attribute__((address_space(3))) unsigned lds_u32;
             typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
             typedef __attribute__((address_space(3))) u32x4_t lds_u128;
-            // group g = 8 lanes; its 8x8 block sits at g*72 dwords (rows of 8 dwords: 16-byte aligned for the lane = point side, and the
-            // transposed side -- lane (g, p) touches dword g*72 + k*8 + p -- spreads a half-wave over all 32 banks)
-            lds_u32* xs = (lds_u32*)&sh.hist[tid >> 6][0] + ((tid & 63) >> 3) * 72;
-            const int p8 = (tid & 7) * 8, pp = tid & 7;
+            // (upper half of sh.hist; row k of group g is stored at row (k + g) & 7, so that the transposed side -- lane (g, p) touches row k,
+            // column p -- spreads a half-wave over all 32 banks without padding, and the lane = point side stays 16-byte aligned)
+            const int gg = (tid & 63) >> 3, pp = tid & 7;
+            lds_u32* xs = (lds_u32*)&sh.hist[0][0] + TC * FW_HP_WORDS + (tid >> 6) * 512 + gg * 64;
+            const int p8 = ((pp + gg) & 7) * 8;
             { u32x4_t w0 = {idx[0], idx[1], idx[2], idx[3]}; *(lds_u128*)(xs + p8) = w0; }
             { u32x4_t w1 = {idx[4], idx[5], idx[6], idx[7]}; *(lds_u128*)(xs + p8 + 4) = w1; }
             wave_sync_lds();
             unsigned t[NT], c[NT];
 #pragma unroll
-            for (int k = 0; k < NT; k++) t[k] = xs[k * 8 + pp];
+            for (int k = 0; k < NT; k++) t[k] = xs[((k + gg) & 7) * 8 + pp];
 #pragma unroll
             for (int k = 0; k < NT; k++) c[k] = T.code[t[k]];
 #pragma unroll
-            for (int k = 0; k < NT; k++) xs[k * 8 + pp] = c[k];
+            for (int k = 0; k < NT; k++) xs[((k + gg) & 7) * 8 + pp] = c[k];
             wave_sync_lds();
             const u32x4_t ca = *(lds_u128*)(xs + p8), cb = *(lds_u128*)(xs + p8 + 4);
             c[0] = ca.x; c[1] = ca.y; c[2] = ca.z; c[3] = ca.w; c[4] = cb.x; c[5] = cb.y; c[6] = cb.z; c[7] = cb.w;
-#pragma unroll
-            for (int j = 0; j < NT; j++) v[j] = dt_decode(T, idx[j], c[j], lut_lds);
-        } else if (T.code) {
+            decode_all(c);
+        } else
+#endif
+        if (T.code) {
             // coded grid: 2-byte gathers (half the cache lines of the float grid), then the value from the LUT
             unsigned c[NT];
 #pragma unroll
             for (int j = 0; j < NT; j++) c[j] = T.code[DBG_ON(T, 2) ? (idx[j] & 1023u) : idx[j]];
-#pragma unroll
-            for (int j = 0; j < NT; j++) v[j] = dt_decode(T, idx[j], c[j], lut_lds);
+            decode_all(c);
         } else {
 #pragma unroll
             for (int j = 0; j < NT; j++) v[j] = T.dist[DBG_ON(T, 2) ? (idx[j] & 1023u) : idx[j]];
         }
         if (__any((int)oob)) {
+#ifdef GOICP_OOB2
+            if (XP && !OCT && row_mode) {
+                // a row of x-neighbours: the y / z parts of the extension are shared, one cell computation per out-of-grid cube, integers from there on
+                const int yu = cell_of(Y + sh.cen[0][1], T.yMin, T.scale), zu = cell_of(Z + sh.cen[0][2], T.zMin, T.scale);
+                const int gb = grid_off(yu, S), gc = grid_off(zu, S);
+                const int bc = gb * gb + gc * gc;
+#pragma unroll
+                for (int j = 0; j < NT; j++) {
+                    if ((oob >> j) & 1u) {
+                        const int ga = grid_off(cell_of(X + sh.cen[j][0], T.xMin, T.scale), S);
+                        v[j] = dt_finish_n(T, v[j], ga * ga + bc);
+                    }
+                }
+            } else
+#endif
+            {
 #pragma unroll
             for (int j = 0; j < NT; j++) {
                 if ((oob >> j) & 1u) {
                     float ext; (void)dt_index(T, X + sh.cen[j][0], Y + sh.cen[j][1], Z + sh.cen[j][2], ext);
                     v[j] = dt_finish(T, v[j], ext);
                 }
+            }
             }
         }
 #pragma unroll
@@ -614,12 +710,227 @@ __device__ __forceinline__ void sweep_tile(const DevTables& T, TileShm<BLOCK>& s
             if (JIT) asm volatile("" : "+v"(d));           // the residual is formed HERE (otherwise the compiler may sink these operations to the
             r[j][m] = d;                                   // first use and keep value, weight and radius alive instead: registers, spills)
         }
+        if constexpr (XP) {
+            // fixed-window histogram of the first selection, accumulated here beside the outstanding gathers (the caller has cleared it: fw_hist_reset)
+            if (T.doTrim) {
+                const bool valid = tid + m * BLOCK < Nd;
+#pragma unroll
+                for (int j = 0; j < NT; j++) fw_add(j, r[j][m], valid);
+            }
+        }
         if (JIT) __builtin_amdgcn_sched_barrier(0);        // keep the point fetches one ahead instead of all up front
     }
+    if constexpr (XP) { if (T.doTrim) fw_flush(); }
     TSTAMP(0);
     // everything behind the gathers (selection + sums -> sh.ub / sh.lb) as one block, so that the fused form can run it twice on the same
     // distance values: first for the call without rotation uncertainty, then again after subtracting the radius of the other call
-    auto finish = [&]() __attribute__((always_inline)) {      // (out of line the residual registers would go through scratch memory)
+    auto finish = [&](const bool have_hist) __attribute__((always_inline)) {      // (out of line the residual registers would go through scratch memory)
+    if constexpr (XP) {
+    if (T.doTrim) {
+        // fixed-window selection (see fw_hist_reset): four workgroup barriers when the histogram came with the gathers, six otherwise
+        const int wv = tid >> 6, ln = tid & 63;
+        constexpr int NW = BLOCK / 64;
+        typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
+        typedef __attribute__((address_space(3))) u32x4_t lds_u128;
+        if (!have_hist) {
+            __syncthreads();                          // (every wave is done with the bounds / flags of the previous selection)
+            fw_hist_reset(sh);
+            __syncthreads();
+#pragma unroll
+            for (int m = 0; m < PPT; m++) {
+                const bool valid = tid + m * BLOCK < Nd;
+#pragma unroll
+                for (int j = 0; j < NT; j++) fw_add(j, r[j][m], valid);
+            }
+            fw_flush();
+        }
+        __syncthreads();                                                            // all adds are in
+        TSTAMP(2);
+        for (int j = wv; j < NT; j += NW) {             // one wave scans the 1024 bins of a cube: 16 per lane = two 16-byte reads
+            const lds_u128* hp = (const lds_u128*)&sh.hist[0][0] + j * (FW_HP_WORDS / 4) + 2 * ln;
+            const u32x4_t wa = hp[0], wb = hp[1];
+            unsigned c[16]; int mine = 0;
+            c[0] = wa.x & 0xFFFFu; c[1] = wa.x >> 16; c[2] = wa.y & 0xFFFFu; c[3] = wa.y >> 16; c[4] = wa.z & 0xFFFFu; c[5] = wa.z >> 16; c[6] = wa.w & 0xFFFFu; c[7] = wa.w >> 16;
+            c[8] = wb.x & 0xFFFFu; c[9] = wb.x >> 16; c[10] = wb.y & 0xFFFFu; c[11] = wb.y >> 16; c[12] = wb.z & 0xFFFFu; c[13] = wb.z >> 16; c[14] = wb.w & 0xFFFFu; c[15] = wb.w >> 16;
+#pragma unroll
+            for (int q = 0; q < 16; q++) mine += (int)c[q];
+            int incl = mine;
+#pragma unroll
+            for (int off = 1; off < 64; off <<= 1) { const int t = __shfl_up(incl, off, 64); if (ln >= off) incl += t; }
+            const int zc = sh.zc[j];
+            const int rank = T.inlierNum - 1;
+            if (rank < zc) {                                  // the threshold is one of the zeros
+                if (ln == 0) { sh.prefix[j] = 0u; sh.rem[j] = rank; sh.ncand[j] = -1; }
+                continue;
+            }
+            const int rem = rank - zc;
+            const unsigned long long over = __ballot(incl > rem);
+            const int owner = over ? __ffsll((long long)over) - 1 : 63;
+            if (ln == owner) {
+                int rr = rem - (incl - mine);
+                int b = 0;
+#pragma unroll
+                for (int q = 0; q < 15; q++) { if (b == q && rr >= (int)c[q]) { rr -= (int)c[q]; b = q + 1; } }
+                unsigned cb = c[0];
+#pragma unroll
+                for (int q = 1; q < 16; q++) if (b == q) cb = c[q];
+                const int bin = 16 * ln + b;
+                // threshold below the window (bin 0 also holds everything under 2^-12), above it (bin 1023 holds everything from 2^4 on), or in a
+                // crowded bin: the generic byte passes decide
+                if (bin == 0 || (bin == 1023 && ((sh.himask >> j) & 1u)) || cb > CAND_CAP) sh.fallback = 1;
+                sh.prefix[j] = (unsigned)(FW_KBASE + bin) << FW_SHIFT;
+                sh.rem[j] = rr;                               // rank among the members of the threshold bin
+            }
+        }
+        __syncthreads();
+        TSTAMP(3);
+        if (!sh.fallback) {
+            // one pass over the registers: everything below the threshold bin goes into the sums (lane-local float partials of <= PPT addends, fp64
+            // across lanes), the bin's members (a handful) into the candidate list
+#pragma unroll
+            for (int j = 0; j < NT; j++) {
+                const unsigned pk = sh.prefix[j] >> FW_SHIFT;
+                const bool known = sh.ncand[j] < 0;           // threshold already known (zero): nothing below it
+                const float mtd = sh.mtd[j];
+                float fub = 0.f, flb = 0.f;
+#pragma unroll
+                for (int m = 0; m < PPT; m++) {
+                    const float d = r[j][m];
+                    const unsigned bits = __float_as_uint(d);
+                    const bool valid = tid + m * BLOCK < Nd && bits != 0u;      // zeros add nothing to either sum
+                    const unsigned key = bits >> FW_SHIFT;
+                    const bool in = valid && key < pk;
+                    const float e = d - mtd;
+                    const float tu = T.norm == 2 ? d * d : (T.norm == 1 ? d : 0.f);
+                    const float tl = T.norm == 2 ? e * e : (T.norm == 1 ? e : 0.f);
+                    fub += in ? tu : 0.f;
+                    flb += (in && e > 0.f) ? tl : 0.f;
+                    if (valid && !known && key == pk) { const int pos = atomicAdd(&sh.ncand[j], 1); if (pos < CAND_CAP) sh.cand[j][pos] = bits; }
+                }
+                const double u = wave_sum((double)fub), l = wave_sum((double)flb);
+                if (ln == 0) { sh.red[wv][2 * j] = u; sh.red[wv][2 * j + 1] = l; }
+            }
+            __syncthreads();
+            TSTAMP(4);
+            // wave j finishes cube j: low 17 bits of the threshold by bisection over the candidates; the candidates below it and the copies of the
+            // threshold that belong to the inlier set join the partial sums of all waves
+            for (int j = wv; j < NT; j += NW) {
+                const int nc = sh.ncand[j];
+                const float mtd = sh.mtd[j];
+                unsigned pre = sh.prefix[j]; int remj = sh.rem[j];
+                double cu = 0.0, cl = 0.0;
+                if (nc >= 0) {
+                    const bool v0 = ln < nc, v1 = ln + 64 < nc;
+                    const unsigned c0 = v0 ? sh.cand[j][ln] : 0u, c1 = v1 ? sh.cand[j][ln + 64] : 0u;
+#pragma unroll
+                    for (int b = FW_SHIFT - 1; b >= 0; b--) {
+                        const unsigned cnd = pre | (1u << b);
+                        const int cnt = __popcll(__ballot(v0 && c0 < cnd)) + __popcll(__ballot(v1 && c1 < cnd));
+                        if (cnt <= remj) pre = cnd;               // the rem-th member is >= cnd
+                    }
+                    const int less = __popcll(__ballot(v0 && c0 < pre)) + __popcll(__ballot(v1 && c1 < pre));
+                    remj -= less;                                 // rank among the copies of the threshold
+                    // (a lane's two candidate terms are added in double: which members of the bin share a lane depends on the order of the LDS
+                    // adds that collected them, and a float sum of two terms would round differently from run to run)
+                    if (v0 && c0 < pre) { const float d = __uint_as_float(c0), e = d - mtd; cu += (double)(T.norm == 2 ? d * d : (T.norm == 1 ? d : 0.f)); if (e > 0.f) cl += (double)(T.norm == 2 ? e * e : (T.norm == 1 ? e : 0.f)); }
+                    if (v1 && c1 < pre) { const float d = __uint_as_float(c1), e = d - mtd; cu += (double)(T.norm == 2 ? d * d : (T.norm == 1 ? d : 0.f)); if (e > 0.f) cl += (double)(T.norm == 2 ? e * e : (T.norm == 1 ? e : 0.f)); }
+                }
+                cu += ln < NW ? sh.red[ln][2 * j] : 0.0;
+                cl += ln < NW ? sh.red[ln][2 * j + 1] : 0.0;
+                double u = wave_sum(cu), l = wave_sum(cl);
+                if (ln == 0) {
+                    const float d = __uint_as_float(pre);
+                    const float e = d - mtd;
+                    const double n = (double)(remj + 1);          // copies of the threshold inside the inlier set
+                    if (T.norm == 2) { u += n * (double)(d * d); if (e > 0.f) l += n * (double)(e * e); }
+                    else if (T.norm == 1) { u += n * (double)d; if (e > 0.f) l += n * (double)e; }
+                    sh.ub[j] = (float)u; sh.lb[j] = (float)l;
+                }
+            }
+            __syncthreads();
+            TSTAMP(5);
+#ifdef GOICP_TILE_STAMPS
+            if (stamp && (DUAL ? !have_hist : have_hist)) { atomicAdd(&T.dbg_times[7], 1ull); atomicAdd(&T.dbg_times[8], wall_clock64() - tw0_); }
+#endif
+            return;
+        }
+        // generic path: four byte passes over the residual registers, MSB first (256-bin histograms in the rows of sh.hist -- the fixed-window
+        // histograms and the transposition scratch are not needed any more), then the order-free sums below
+        unsigned thr[NT]; int below[NT];
+        if (tid < NT) { sh.prefix[tid] = 0u; sh.rem[tid] = T.inlierNum - 1; }
+        for (int pass = 3; pass >= 0; pass--) {
+            __syncthreads();
+            for (int k = tid; k < NT * 256; k += BLOCK) sh.hist[k >> 8][k & 255] = 0u;
+            __syncthreads();
+            const unsigned himask = pass == 3 ? 0u : (0xFFFFFFFFu << (8 * (pass + 1)));
+#pragma unroll
+            for (int m = 0; m < PPT; m++) {
+                const bool valid = tid + m * BLOCK < Nd;
+#pragma unroll
+                for (int j = 0; j < NT; j++) {
+                    const unsigned bits = __float_as_uint(r[j][m]);
+                    const bool take = valid && ((bits ^ sh.prefix[j]) & himask) == 0u;
+                    hist_add(sh.hist[j], (bits >> (8 * pass)) & 255u, take, ln);
+                }
+            }
+            __syncthreads();
+            for (int j = wv; j < NT; j += NW) {
+                const unsigned c0 = sh.hist[j][4 * ln], c1 = sh.hist[j][4 * ln + 1], c2 = sh.hist[j][4 * ln + 2], c3 = sh.hist[j][4 * ln + 3];
+                const int mine = (int)(c0 + c1 + c2 + c3);
+                int incl = mine;
+#pragma unroll
+                for (int off = 1; off < 64; off <<= 1) { const int t = __shfl_up(incl, off, 64); if (ln >= off) incl += t; }
+                const int rem = sh.rem[j];
+                const unsigned long long over = __ballot(incl > rem);
+                const int owner = over ? __ffsll((long long)over) - 1 : 63;
+                if (ln == owner) {
+                    int rr = rem - (incl - mine);
+                    unsigned dgt = 4u * ln;
+                    if (rr >= (int)c0) { rr -= (int)c0; dgt++; if (rr >= (int)c1) { rr -= (int)c1; dgt++; if (rr >= (int)c2) { rr -= (int)c2; dgt++; } } }
+                    sh.prefix[j] |= dgt << (8 * pass);
+                    sh.rem[j] = rr;
+                }
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < NT; j++) { thr[j] = sh.prefix[j]; below[j] = T.inlierNum - 1 - sh.rem[j]; }   // rem = rank among the copies of thr
+#pragma unroll
+        for (int j = 0; j < NT; j++) {
+            float fub = 0.f, flb = 0.f;
+            const float mtd = sh.mtd[j];
+            const unsigned thrj = thr[j];
+#pragma unroll
+            for (int m = 0; m < PPT; m++) {
+                const float d = r[j][m];
+                const bool in = (tid + m * BLOCK < Nd) && __float_as_uint(d) < thrj;
+                const float e = d - mtd;
+                const float tu = T.norm == 2 ? d * d : (T.norm == 1 ? d : 0.f);
+                const float tl = T.norm == 2 ? e * e : (T.norm == 1 ? e : 0.f);
+                fub += in ? tu : 0.f;
+                flb += (in && e > 0.f) ? tl : 0.f;
+            }
+            const double u = wave_sum((double)fub), l = wave_sum((double)flb);
+            if (ln == 0) { sh.red[wv][2 * j] = u; sh.red[wv][2 * j + 1] = l; }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < NT; j++) {
+            if (tid == j) {
+                double u = 0.0, l = 0.0;
+                for (int w = 0; w < NW; w++) { u += sh.red[w][2 * j]; l += sh.red[w][2 * j + 1]; }
+                const float d = __uint_as_float(thr[j]);
+                const float e = d - sh.mtd[j];
+                const double n = (double)(T.inlierNum - below[j]);          // the copies of the threshold value that belong to the inlier set
+                if (T.norm == 2) { u += n * (double)(d * d); if (e > 0.f) l += n * (double)(e * e); }
+                else if (T.norm == 1) { u += n * (double)d; if (e > 0.f) l += n * (double)e; }
+                sh.ub[j] = (float)u; sh.lb[j] = (float)l;
+            }
+        }
+        __syncthreads();
+        return;
+    }
+    }
     // (the just-in-time kernels carry the reference-order branches only in their parity_mode 2 instantiation: beside the fast path they cost it registers)
     if ((JIT ? XBIG : (BLOCK * PPT <= 1024 && T.exact)) && T.doTrim) {
         // parity mode, trimmed: residual rows to LDS, one lane per cube runs the reference's selection (same swaps, same final
@@ -710,10 +1021,7 @@ __device__ __forceinline__ void sweep_tile(const DevTables& T, TileShm<BLOCK>& s
         const int wv = tid >> 6, ln = tid & 63;
         constexpr int NW = BLOCK / 64;
         // Five workgroup barriers for the whole selection + sums. Everything initialised here is first used after barrier 1.
-        if (XP) {           // wave w clears row w: its own transposition scratch, which no other wave may touch before this wave is done with it
-            for (int k = ln; k < 1024; k += 64) sh.hist[wv][k] = 0u;
-            for (int j = NW + wv; j < NT; j += NW) for (int k = ln; k < 1024; k += 64) sh.hist[j][k] = 0u;
-        } else for (int k = tid; k < NT * 1024; k += BLOCK) (&sh.hist[0][0])[k] = 0u;
+        for (int k = tid; k < NT * 1024; k += BLOCK) (&sh.hist[0][0])[k] = 0u;
         if (tid < NT) { sh.prefix[tid] = 0u; sh.rem[tid] = T.inlierNum - 1; sh.zc[tid] = 0; sh.ncand[tid] = 0; }
         if (tid == 0) sh.fallback = 0;
         // (1) largest residual per cube (fixes the 8-octave window of the histogram): per-wave maxima by plain stores
@@ -857,7 +1165,9 @@ __device__ __forceinline__ void sweep_tile(const DevTables& T, TileShm<BLOCK>& s
             }
             __syncthreads();                                                        // barrier 5
             TSTAMP(5);
-            if (stamp) atomicAdd(&T.dbg_times[7], 1ull);
+#ifdef GOICP_TILE_STAMPS
+            if (stamp) { atomicAdd(&T.dbg_times[7], 1ull); atomicAdd(&T.dbg_times[8], wall_clock64() - tw0_); }
+#endif
             return;
         }
         const bool generic = sh.fallback != 0;
@@ -942,7 +1252,7 @@ __device__ __forceinline__ void sweep_tile(const DevTables& T, TileShm<BLOCK>& s
     }
     __syncthreads();
     };
-    finish();
+    finish(true);
     if constexpr (DUAL) {
         // (two call sites rather than a loop: inside a loop the compiler hoists the block's lane-constant addresses and spills the residuals)
         if (tid < NT) { sh.ub2[tid] = sh.ub[tid]; sh.lb2[tid] = sh.lb[tid]; }        // (ordered by the barriers of the next finish())
@@ -955,7 +1265,7 @@ __device__ __forceinline__ void sweep_tile(const DevTables& T, TileShm<BLOCK>& s
 #pragma unroll
             for (int j = 0; j < NT; j++) { float d = r[j][m] - rh; if (d < 0.f) d = 0.f; r[j][m] = d; }
         }
-        finish();
+        finish(false);
     }
 }
 

@@ -230,7 +230,7 @@ __global__ __launch_bounds__(512, 4) void k_eval_cubes_geo(DevTables T, const fl
     // (wave-uniform: kept in scalar registers, so that the output addresses formed from them at the end cost no vector registers in between)
     g.x = __builtin_amdgcn_readfirstlane(g.x); g.y = __builtin_amdgcn_readfirstlane(g.y); g.z = __builtin_amdgcn_readfirstlane(g.z); g.w = __builtin_amdgcn_readfirstlane(g.w);
     const float4* __restrict__ rot = rot_all + (size_t)g.x * Nd;
-    const float* __restrict__ rho = g.y >= 0 ? T.maxRotDis + (size_t)g.y * Nd : nullptr;
+    const float* __restrict__ rho = g.y >= 0 ? (T.perm ? T.maxRotDisP : T.maxRotDis) + (size_t)g.y * Nd : nullptr;      // (slot clouds of this kernel are stored in T.perm order)
     if (tid < TC) {
         const int j = tid, c = min(base + j, n - 1);          // the tail tile re-evaluates the last cube
         const float x = cubes[4 * c], y = cubes[4 * c + 1], z = cubes[4 * c + 2], w = cubes[4 * c + 3];
@@ -238,6 +238,7 @@ __global__ __launch_bounds__(512, 4) void k_eval_cubes_geo(DevTables T, const fl
         sh.cen[j][0] = x + w / 2; sh.cen[j][1] = y + w / 2; sh.cen[j][2] = z + w / 2;
         sh.mtd[j] = (float)(SQRT3_D / 2.0 * w);
     }
+    if (!XBIG && T.doTrim) fw_hist_reset(sh);           // the first selection's histogram is filled beside the gathers (sweep_tile<..., XP>)
     __syncthreads();
     // every lane decides for itself whether the tile is a row of x-neighbours (broadcast LDS reads, no second barrier)
     bool row = true;

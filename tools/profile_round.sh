@@ -5,7 +5,7 @@
 # Counters are collected in passes of their own with --kernel-trace only (no other trace domains), each within the per-block slot
 # limits of /opt/skills/guides/MI355X_MICROARCH.md (TCC: 4 slots, FETCH_SIZE = 3, WRITE_SIZE = 2; SQ: 8).
 set -o pipefail
-TAG=${1:-r02}
+TAG=${1:-r03}
 SHAPE=${2:-c3}
 R=$PWD
 export TMPDIR=/tmp

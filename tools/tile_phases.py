@@ -25,6 +25,15 @@ for _ in range(3):
 e.synchronize()
 d = np.zeros(16, np.uint64); e.L.goicp_engine_debug_times(e.h, d.ctypes.data_as(C.c_void_p))
 tiles = float(d[7]); c = d[:7].astype(float) / max(tiles, 1)
+wall_us = float(d[8]) / max(tiles, 1) / 100.0
+import time
+t0 = time.perf_counter()
+for _ in range(20):
+    e.eval_cubes_multi_dev(sl, lv, cubes.data_ptr(), n, ub.data_ptr(), lb.data_ptr())
+e.synchronize(); ms = (time.perf_counter() - t0) / 20 * 1e3
+ntile = 585 * 16
+print("kernel %s: %.3f ms per launch; a stamped tile takes %.1f us of wall time (%.0f cycles -> %.2f GHz); tiles in flight = tiles x tile time / launch time = %.0f (2 x 256 = 512 if two workgroups share every CU)"
+      % (e.eval_kernel_name(), ms, wall_us, c.sum(), c.sum() / max(wall_us, 1e-9) / 1e3, ntile * wall_us / (ms * 1e3)))
 print("stamped tiles %d; cycles per tile (fused pairs: both selections summed): gather+residuals %.0f | max %.0f | histogram %.0f | scan %.0f | collect+sums %.0f | finish %.0f | radius pass %.0f | total %.0f" % (tiles, c[0], c[1], c[2], c[3], c[4], c[5], c[6], c.sum()))
 
 for variant in ():
