@@ -75,7 +75,7 @@ __global__ void k_build_codes(const float* __restrict__ dist, const float* __res
 __global__ void k_rotate(DevTables T, const float* __restrict__ R, float4* __restrict__ out) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= T.Nd) return;
-    const int s = T.perm ? T.perm[i] : i;
+    const int s = src_point(T, i);
     const float x = T.dxyz[3 * s], y = T.dxyz[3 * s + 1], z = T.dxyz[3 * s + 2];
     float4 p;
     p.x = R[0] * x + R[1] * y + R[2] * z;
@@ -641,7 +641,6 @@ extern "C" int goicp_engine_create(const goicp_engine_desc* d, goicp_engine** ou
     if (sparse) T.dist = (const float*)d->dt_dist_dev;        // adopted in place (owned by the caller's goicp_dtgpu handle)
     else { float* p_dist; CR(dev_upload(h, d->dt_dist, ncell, &p_dist)); T.dist = p_dist; }
     T.code = nullptr; T.lut = nullptr;
-    T.extq = nullptr; T.extq_n = 0;
     std::vector<float> lut;                     // (sources of deferred uploads live to the end of this function)
     std::vector<int> occ_cells, occ_ptr(1, 0), occ_pts;
     std::vector<uint16_t> occ_mask;
@@ -766,8 +765,8 @@ extern "C" int goicp_engine_create(const goicp_engine_desc* d, goicp_engine** ou
     h->jit_eval = (h->block == 1024 && h->ppt >= 2 && !T.exact && !T.use_compat && !T.use_fpfh && !env_is_zero("GOICP_JIT")) ? 1 : 0;
     T.perm = nullptr; T.maxRotDisP = nullptr;
     std::vector<int> perm; std::vector<float> mrdP;
-    if (h->jit_eval && !T.exact_big && !env_is_zero("GOICP_SORT")) {
-        // metric kernel: the slot clouds are stored by decreasing norm. A look-up leaves the grid only for points far from the centre, and a wave
+    if (d->Nd > 1024 && !T.exact && !T.exact_big && !T.exact_stream && !T.use_compat && !T.use_fpfh && !env_is_zero("GOICP_SORT")) {
+        // order-free engines (every sweep and search kernel of a geometric run above 1024 points): the clouds are stored by decreasing norm. A look-up leaves the grid only for points far from the centre, and a wave
         // pays for the out-of-grid extension (double-precision sqrt / divide) whenever ONE of its lanes needs it: with the far points next to each
         // other few waves do. The sums of this path are order-free (fp64), the inlier selection is a multiset: results do not depend on the order.
         perm.resize((size_t)d->Nd);
@@ -892,7 +891,7 @@ extern "C" const char* goicp_engine_eval_kernel_name(goicp_engine* h) {
     char buf[96];
     const bool jit = h->jit_eval != 0;
     if (h->streamed) snprintf(buf, sizeof buf, "k_eval_cubes_stream<%d,%s>", h->T.Nd > 16384 ? 1024 : 512, (h->last_fused ? "true" : "false"));
-    else if (jit) snprintf(buf, sizeof buf, "k_eval_cubes_geo<%d,%s,%s>", 2 * h->ppt, h->npairs > 0 ? "true" : "false", h->T.exact_big ? "true" : "false");   // (DUAL: the group table of the last multi-group call paired up; XBIG: parity_mode 2)
+    else if (jit) snprintf(buf, sizeof buf, "k_eval_cubes_geo<%d,%s,%s,%d>", 2 * h->ppt, h->npairs > 0 ? "true" : "false", h->T.exact_big ? "true" : "false", (!h->T.exact_big && h->T.norm == 2) ? 2 : 0);   // (DUAL: the group table of the last multi-group call paired up; XBIG: parity_mode 2)
     else snprintf(buf, sizeof buf, "k_eval_cubes<%d,%d,8,false>", h->block, h->ppt);
     h->kernel_name = buf;
     return h->kernel_name.c_str();

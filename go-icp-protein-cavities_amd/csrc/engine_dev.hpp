@@ -37,7 +37,6 @@ struct DevTables {
     // 2-byte coded copy of the grid (see k_build_codes): code = squared cell distance d2 when dist == lut[d2] bit for bit and d2 < 65535,
     // else 0xFFFF (the value is then read from `dist`). Twice the cells per cache line of the gather stream; null = not built.
     const uint16_t* code; const float* lut;
-    const double* extq; int extq_n;   // out-of-grid extension: (double)sqrtf((float)n) / scale for n = a*a + b*b + c*c < extq_n (jly_3ddt.cpp:1150-1190), tabulated on the host
     const uint16_t* cmask;
     const int* occ;          // [S^3] compact id of the nearest occupied cell, -1 if none
     const int* occ_ptr;      // [nOcc+1]
@@ -66,6 +65,10 @@ struct DevTables {
 };
 
 struct __attribute__((aligned(8))) HeapNode { float x, y, z, w, ub, lb; };
+
+// order-free engines (geometric error above 1024 points, not parity_mode 2) keep their clouds by decreasing norm: position i holds point T.perm[i]
+__device__ __forceinline__ int src_point(const DevTables& T, int i) { return T.perm ? T.perm[i] : i; }
+__device__ __forceinline__ const float* rho_rows(const DevTables& T) { return T.perm ? T.maxRotDisP : T.maxRotDis; }
 
 // ---------------------------------------------------------------------------------------------
 // device helpers
@@ -109,12 +112,6 @@ __device__ __forceinline__ float dt_ext_raw(int x, int y, int z, int S) {
 __device__ __forceinline__ float dt_finish(const DevTables& T, float v, float ext) {
     if (ext > 0.f) v = (float)((double)ext / T.scale + (double)v);      // float sqrt, double divide and add, rounded to float
     return v;
-}
-// the same from the integer squared extension length n = a*a + b*b + c*c (a, b, c: cells beyond the grid; the float products and sums of the
-// reference are exact for these small integers): sqrtf((float)n) / scale comes from a host-built table for small n, bit for bit the same quotient
-__device__ __forceinline__ float dt_finish_n(const DevTables& T, float v, int n) {
-    const double q = (double)sqrtf((float)n) / T.scale;      // (a host-built table of these quotients in global memory measured far slower: a dependent load per cube inside the gather loop)
-    return (float)(q + (double)v);
 }
 __device__ __forceinline__ float dt_lookup(const DevTables& T, float X, float Y, float Z) {
     float ext;
@@ -516,7 +513,8 @@ __device__ __forceinline__ void fw_hist_reset(TileShm<BLOCK>& sh) {   // every l
 // lanes of a group swap their cell indices through LDS (the wave's own 4 KB row of sh.hist, which finish() clears afterwards) so that
 // instruction k carries the 8 cells of point k of every group: 8 lanes share 1-3 lines, one request each. The codes travel back the same way.
 // Values, arithmetic and the residual registers are untouched (lane = point everywhere else).
-template <int BLOCK, int PPT, bool OCT, int NT, bool JIT = false, bool DUAL = false, bool XBIG = false /* JIT kernels: the parity_mode 2 instantiation (rows in HBM) */, bool XP = false>
+template <int BLOCK, int PPT, bool OCT, int NT, bool JIT = false, bool DUAL = false, bool XBIG = false /* JIT kernels: the parity_mode 2 instantiation (rows in HBM) */, bool XP = false,
+          int NORM = 0 /* XP path: 2 or 1 = the norm is known at compile time (no per-value selects), 0 = read T.norm */>
 __device__ __forceinline__ void sweep_tile(const DevTables& T, TileShm<BLOCK>& sh, const float (&px)[PPT], const float (&py)[PPT],
                                            const float (&pz)[PPT], const float (&pw)[PPT], const float (&prho)[PPT], bool use_rho,
                                            float* rbuf /* LDS, exact mode only */, bool row_mode = false /* !OCT: the cubes share y and z */,
@@ -586,11 +584,11 @@ __device__ __forceinline__ void sweep_tile(const DevTables& T, TileShm<BLOCK>& s
     int fw_z[NT]; unsigned fw_hi = 0u;
 #pragma unroll
     for (int j = 0; j < NT; j++) fw_z[j] = 0;
-    auto fw_add = [&](int j, float d, bool valid) __attribute__((always_inline)) {
+    auto fw_add = [&](int j, float d) __attribute__((always_inline)) {
         typedef __attribute__((address_space(3))) unsigned lds_u32;
         const unsigned bits = __float_as_uint(d);
-        const bool nz = valid && bits != 0u;
-        fw_z[j] += __popcll(__ballot(valid && bits == 0u));
+        const bool nz = bits != 0u;
+        fw_z[j] += __popcll(__ballot(!nz));            // (includes the lanes past Nd: BLOCK * PPT - Nd of them per cube, subtracted at the scan)
         int k = (int)(bits >> FW_SHIFT) - FW_KBASE;
         fw_hi |= (__ballot(nz && k > 1023) ? 1u : 0u) << j;
         k = min(max(k, 0), 1023);
@@ -613,12 +611,12 @@ __device__ __forceinline__ void sweep_tile(const DevTables& T, TileShm<BLOCK>& s
         float X, Y, Z, W, RH;
         if (JIT) {
             X = pnext.x; Y = pnext.y; Z = pnext.z; W = pnext.w; RH = rnext;
+            if (XP && tid + m * BLOCK >= Nd) W = 0.f;      // lanes past Nd: residual exactly 0 (weight 0, radius >= 0); no per-value validity tests below
             if (m + 1 < PPT) { const int in = min(tid + (m + 1) * BLOCK, Nd - 1); pnext = jit_rot[in]; rnext = jit_rho ? jit_rho[in] : 0.f; }
         } else { X = px[m]; Y = py[m]; Z = pz[m]; W = pw[m]; RH = prho[m]; }
         unsigned idx[NT]; float v[NT];
         const unsigned oob = cells(X, Y, Z, idx);
         auto decode_all = [&](const unsigned (&c)[NT]) __attribute__((always_inline)) {
-#ifdef GOICP_DECODE2
             // codes below LUT_LDS (within 90 cells of the model: nearly all) come from the LDS table without a branch per value; the rest --
             // far cells through the global table, escapes through the float grid -- are patched under ONE wave-wide test
             if (XP && lut_lds) {
@@ -635,7 +633,6 @@ __device__ __forceinline__ void sweep_tile(const DevTables& T, TileShm<BLOCK>& s
                 }
                 return;
             }
-#endif
 #pragma unroll
             for (int j = 0; j < NT; j++) v[j] = dt_decode(T, idx[j], c[j], lut_lds);
         };
@@ -677,21 +674,6 @@ __device__ __forceinline__ void sweep_tile(const DevTables& T, TileShm<BLOCK>& s
             for (int j = 0; j < NT; j++) v[j] = T.dist[DBG_ON(T, 2) ? (idx[j] & 1023u) : idx[j]];
         }
         if (__any((int)oob)) {
-#ifdef GOICP_OOB2
-            if (XP && !OCT && row_mode) {
-                // a row of x-neighbours: the y / z parts of the extension are shared, one cell computation per out-of-grid cube, integers from there on
-                const int yu = cell_of(Y + sh.cen[0][1], T.yMin, T.scale), zu = cell_of(Z + sh.cen[0][2], T.zMin, T.scale);
-                const int gb = grid_off(yu, S), gc = grid_off(zu, S);
-                const int bc = gb * gb + gc * gc;
-#pragma unroll
-                for (int j = 0; j < NT; j++) {
-                    if ((oob >> j) & 1u) {
-                        const int ga = grid_off(cell_of(X + sh.cen[j][0], T.xMin, T.scale), S);
-                        v[j] = dt_finish_n(T, v[j], ga * ga + bc);
-                    }
-                }
-            } else
-#endif
             {
 #pragma unroll
             for (int j = 0; j < NT; j++) {
@@ -713,9 +695,8 @@ __device__ __forceinline__ void sweep_tile(const DevTables& T, TileShm<BLOCK>& s
         if constexpr (XP) {
             // fixed-window histogram of the first selection, accumulated here beside the outstanding gathers (the caller has cleared it: fw_hist_reset)
             if (T.doTrim) {
-                const bool valid = tid + m * BLOCK < Nd;
 #pragma unroll
-                for (int j = 0; j < NT; j++) fw_add(j, r[j][m], valid);
+                for (int j = 0; j < NT; j++) fw_add(j, r[j][m]);
             }
         }
         if (JIT) __builtin_amdgcn_sched_barrier(0);        // keep the point fetches one ahead instead of all up front
@@ -729,6 +710,7 @@ __device__ __forceinline__ void sweep_tile(const DevTables& T, TileShm<BLOCK>& s
     if (T.doTrim) {
         // fixed-window selection (see fw_hist_reset): four workgroup barriers when the histogram came with the gathers, six otherwise
         const int wv = tid >> 6, ln = tid & 63;
+        const int nrm = NORM ? NORM : T.norm;
         constexpr int NW = BLOCK / 64;
         typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
         typedef __attribute__((address_space(3))) u32x4_t lds_u128;
@@ -738,9 +720,8 @@ __device__ __forceinline__ void sweep_tile(const DevTables& T, TileShm<BLOCK>& s
             __syncthreads();
 #pragma unroll
             for (int m = 0; m < PPT; m++) {
-                const bool valid = tid + m * BLOCK < Nd;
 #pragma unroll
-                for (int j = 0; j < NT; j++) fw_add(j, r[j][m], valid);
+                for (int j = 0; j < NT; j++) fw_add(j, r[j][m]);
             }
             fw_flush();
         }
@@ -757,7 +738,7 @@ __device__ __forceinline__ void sweep_tile(const DevTables& T, TileShm<BLOCK>& s
             int incl = mine;
 #pragma unroll
             for (int off = 1; off < 64; off <<= 1) { const int t = __shfl_up(incl, off, 64); if (ln >= off) incl += t; }
-            const int zc = sh.zc[j];
+            const int zc = sh.zc[j] - (BLOCK * PPT - Nd);     // residuals that are exactly 0, without the lanes past Nd
             const int rank = T.inlierNum - 1;
             if (rank < zc) {                                  // the threshold is one of the zeros
                 if (ln == 0) { sh.prefix[j] = 0u; sh.rem[j] = rank; sh.ncand[j] = -1; }
@@ -793,19 +774,17 @@ __device__ __forceinline__ void sweep_tile(const DevTables& T, TileShm<BLOCK>& s
                 const bool known = sh.ncand[j] < 0;           // threshold already known (zero): nothing below it
                 const float mtd = sh.mtd[j];
                 float fub = 0.f, flb = 0.f;
+                const unsigned pkc = known ? 0xFFFFFFFFu : pk;     // (threshold already known: no candidates)
 #pragma unroll
                 for (int m = 0; m < PPT; m++) {
-                    const float d = r[j][m];
-                    const unsigned bits = __float_as_uint(d);
-                    const bool valid = tid + m * BLOCK < Nd && bits != 0u;      // zeros add nothing to either sum
+                    // zeros (clamped residuals, lanes past Nd) have key 0: they pass the test and add 0 to both sums (mtd >= 0)
+                    const unsigned bits = __float_as_uint(r[j][m]);
                     const unsigned key = bits >> FW_SHIFT;
-                    const bool in = valid && key < pk;
-                    const float e = d - mtd;
-                    const float tu = T.norm == 2 ? d * d : (T.norm == 1 ? d : 0.f);
-                    const float tl = T.norm == 2 ? e * e : (T.norm == 1 ? e : 0.f);
-                    fub += in ? tu : 0.f;
-                    flb += (in && e > 0.f) ? tl : 0.f;
-                    if (valid && !known && key == pk) { const int pos = atomicAdd(&sh.ncand[j], 1); if (pos < CAND_CAP) sh.cand[j][pos] = bits; }
+                    const float dm = key < pk ? r[j][m] : 0.f;
+                    const float em = fmaxf(dm - mtd, 0.f);
+                    fub += nrm == 2 ? dm * dm : (nrm == 1 ? dm : 0.f);
+                    flb += nrm == 2 ? em * em : (nrm == 1 ? em : 0.f);
+                    if (key == pkc) { const int pos = atomicAdd(&sh.ncand[j], 1); if (pos < CAND_CAP) sh.cand[j][pos] = bits; }
                 }
                 const double u = wave_sum((double)fub), l = wave_sum((double)flb);
                 if (ln == 0) { sh.red[wv][2 * j] = u; sh.red[wv][2 * j + 1] = l; }
@@ -832,8 +811,8 @@ __device__ __forceinline__ void sweep_tile(const DevTables& T, TileShm<BLOCK>& s
                     remj -= less;                                 // rank among the copies of the threshold
                     // (a lane's two candidate terms are added in double: which members of the bin share a lane depends on the order of the LDS
                     // adds that collected them, and a float sum of two terms would round differently from run to run)
-                    if (v0 && c0 < pre) { const float d = __uint_as_float(c0), e = d - mtd; cu += (double)(T.norm == 2 ? d * d : (T.norm == 1 ? d : 0.f)); if (e > 0.f) cl += (double)(T.norm == 2 ? e * e : (T.norm == 1 ? e : 0.f)); }
-                    if (v1 && c1 < pre) { const float d = __uint_as_float(c1), e = d - mtd; cu += (double)(T.norm == 2 ? d * d : (T.norm == 1 ? d : 0.f)); if (e > 0.f) cl += (double)(T.norm == 2 ? e * e : (T.norm == 1 ? e : 0.f)); }
+                    if (v0 && c0 < pre) { const float d = __uint_as_float(c0), e = d - mtd; cu += (double)(nrm == 2 ? d * d : (nrm == 1 ? d : 0.f)); if (e > 0.f) cl += (double)(nrm == 2 ? e * e : (nrm == 1 ? e : 0.f)); }
+                    if (v1 && c1 < pre) { const float d = __uint_as_float(c1), e = d - mtd; cu += (double)(nrm == 2 ? d * d : (nrm == 1 ? d : 0.f)); if (e > 0.f) cl += (double)(nrm == 2 ? e * e : (nrm == 1 ? e : 0.f)); }
                 }
                 cu += ln < NW ? sh.red[ln][2 * j] : 0.0;
                 cl += ln < NW ? sh.red[ln][2 * j + 1] : 0.0;
@@ -842,8 +821,8 @@ __device__ __forceinline__ void sweep_tile(const DevTables& T, TileShm<BLOCK>& s
                     const float d = __uint_as_float(pre);
                     const float e = d - mtd;
                     const double n = (double)(remj + 1);          // copies of the threshold inside the inlier set
-                    if (T.norm == 2) { u += n * (double)(d * d); if (e > 0.f) l += n * (double)(e * e); }
-                    else if (T.norm == 1) { u += n * (double)d; if (e > 0.f) l += n * (double)e; }
+                    if (nrm == 2) { u += n * (double)(d * d); if (e > 0.f) l += n * (double)(e * e); }
+                    else if (nrm == 1) { u += n * (double)d; if (e > 0.f) l += n * (double)e; }
                     sh.ub[j] = (float)u; sh.lb[j] = (float)l;
                 }
             }

@@ -33,14 +33,15 @@ __global__ __launch_bounds__(BLOCK, (BLOCK == 256 ? 2 : (JIT ? 4 : 1))) void k_i
     if constexpr (STREAM || JIT) {
         srot = T.srot + (size_t)blockIdx.x * T.NdP;
         srows = T.srows ? T.srows + (size_t)blockIdx.x * (T.exact_stream ? 2 : 1) * TC * T.NdP : nullptr;
-        srho = use_rho ? T.maxRotDis + (size_t)job.rot_level * Nd : nullptr;
+        srho = use_rho ? rho_rows(T) + (size_t)job.rot_level * Nd : nullptr;
         for (int i = tid; i < Nd; i += BLOCK) {
-            const float x = T.dxyz[3 * i], y = T.dxyz[3 * i + 1], z = T.dxyz[3 * i + 2];
+            const int s = src_point(T, i);
+            const float x = T.dxyz[3 * s], y = T.dxyz[3 * s + 1], z = T.dxyz[3 * s + 2];
             float4 p;
             p.x = job.R[0] * x + job.R[1] * y + job.R[2] * z;
             p.y = job.R[3] * x + job.R[4] * y + job.R[5] * z;
             p.z = job.R[6] * x + job.R[7] * y + job.R[8] * z;
-            p.w = T.weights[i];
+            p.w = T.weights[s];
             srot[i] = p;
         }
 #pragma unroll
@@ -48,11 +49,11 @@ __global__ __launch_bounds__(BLOCK, (BLOCK == 256 ? 2 : (JIT ? 4 : 1))) void k_i
         __syncthreads();
     } else {
         float x[PPT], y[PPT], z[PPT], rh[PPT];
-        const float* rho_row = T.maxRotDis + (size_t)(use_rho ? job.rot_level : 0) * Nd;
+        const float* rho_row = rho_rows(T) + (size_t)(use_rho ? job.rot_level : 0) * Nd;
 #pragma unroll
         for (int m = 0; m < PPT; m++) {
-            const int i = min(tid + m * BLOCK, Nd - 1);
-            x[m] = T.dxyz[3 * i]; y[m] = T.dxyz[3 * i + 1]; z[m] = T.dxyz[3 * i + 2]; pw[m] = T.weights[i]; rh[m] = rho_row[i];
+            const int i = min(tid + m * BLOCK, Nd - 1), s = src_point(T, i);
+            x[m] = T.dxyz[3 * s]; y[m] = T.dxyz[3 * s + 1]; z[m] = T.dxyz[3 * s + 2]; pw[m] = T.weights[s]; rh[m] = rho_row[i];
         }
 #pragma unroll
         for (int m = 0; m < PPT; m++) {

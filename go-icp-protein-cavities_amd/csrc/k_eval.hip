@@ -38,13 +38,13 @@ __global__ __launch_bounds__(BLOCK, (BLOCK == 512 ? 4 : 1)) void k_eval_cubes_st
         }
         __syncthreads();
         if (DUAL) {
-            sweep_stream<false, BLOCK>(T, sh, rot_all + (size_t)slot * Nd, nullptr, rows, T.NdP, 0, 0, nullptr, T.maxRotDis + (size_t)rot_level * Nd);
+            sweep_stream<false, BLOCK>(T, sh, rot_all + (size_t)slot * Nd, nullptr, rows, T.NdP, 0, 0, nullptr, rho_rows(T) + (size_t)rot_level * Nd);
             if (tid < TC && base + tid < n) {
                 ub_out[(size_t)row_a * n + base + tid] = sh.ub2[tid]; lb_out[(size_t)row_a * n + base + tid] = sh.lb2[tid];
                 ub_out[(size_t)row_b * n + base + tid] = sh.ub[tid];  lb_out[(size_t)row_b * n + base + tid] = sh.lb[tid];
             }
         } else {
-            sweep_stream<false, BLOCK>(T, sh, rot_all + (size_t)slot * Nd, rot_level >= 0 ? T.maxRotDis + (size_t)rot_level * Nd : nullptr, rows, T.NdP);
+            sweep_stream<false, BLOCK>(T, sh, rot_all + (size_t)slot * Nd, rot_level >= 0 ? rho_rows(T) + (size_t)rot_level * Nd : nullptr, rows, T.NdP);
             if (tid < TC && base + tid < n) { ub_out[(size_t)g * n + base + tid] = sh.ub[tid]; lb_out[(size_t)g * n + base + tid] = sh.lb[tid]; }
         }
         __syncthreads();
@@ -74,13 +74,13 @@ __global__ __launch_bounds__(BLOCK, (JIT ? (NT == 8 ? 4 : (NT == 4 ? 6 : 8)) : 1
     float* fpbuf = fpscratch ? fpscratch + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * NLMAX * Nd : nullptr;
     float px[PPT], py[PPT], pz[PPT], pw[PPT], prho[PPT];
     const bool use_rho = rot_level >= 0;
-    const float* rho_row_jit = use_rho ? T.maxRotDis + (size_t)rot_level * Nd : nullptr;
+    const float* rho_row_jit = use_rho ? rho_rows(T) + (size_t)rot_level * Nd : nullptr;
     if (JIT) {
 #pragma unroll
         for (int m = 0; m < PPT; m++) { px[m] = py[m] = pz[m] = pw[m] = prho[m] = 0.f; }
     } else {   // all loads first (clamped index instead of a branch), one wait for the lot
         float4 p[PPT]; float rh[PPT];
-        const float* rho_row = T.maxRotDis + (size_t)(use_rho ? rot_level : 0) * Nd;
+        const float* rho_row = rho_rows(T) + (size_t)(use_rho ? rot_level : 0) * Nd;
 #pragma unroll
         for (int m = 0; m < PPT; m++) { const int i = min(tid + m * BLOCK, Nd - 1); p[m] = rot[i]; rh[m] = rho_row[i]; }
 #pragma unroll
@@ -199,7 +199,7 @@ __global__ __launch_bounds__(BLOCK) void k_gather_probe(DevTables T, const float
 //               with it, as OuterBnB's two InnerBnB calls per child rotation do (reference jly_goicp.cpp:768,861): one pass of gathers, two
 //               bound pairs per cube (sweep_tile<..., DUAL>). groups[y] = (slot, rot_level of the second call, output row of the first
 //               call, output row of the second).
-template <int PPT, bool DUAL, bool XBIG = false>
+template <int PPT, bool DUAL, bool XBIG = false, int NORM = 0 /* 2: the squared norm compiled in (the common case); 0: T.norm read at run time */>
 __global__ __launch_bounds__(512, 4) void k_eval_cubes_geo(DevTables T, const float4* __restrict__ rot_all, const int4* __restrict__ groups,
                                                            const float* __restrict__ cubes, int n, float* __restrict__ ub_out, float* __restrict__ lb_out,
                                                            int tiles, int ngroups, int xcd_mode, int lin0 /* first workgroup of this launch (chunked launches of the exact mode) */) {
@@ -230,7 +230,7 @@ __global__ __launch_bounds__(512, 4) void k_eval_cubes_geo(DevTables T, const fl
     // (wave-uniform: kept in scalar registers, so that the output addresses formed from them at the end cost no vector registers in between)
     g.x = __builtin_amdgcn_readfirstlane(g.x); g.y = __builtin_amdgcn_readfirstlane(g.y); g.z = __builtin_amdgcn_readfirstlane(g.z); g.w = __builtin_amdgcn_readfirstlane(g.w);
     const float4* __restrict__ rot = rot_all + (size_t)g.x * Nd;
-    const float* __restrict__ rho = g.y >= 0 ? (T.perm ? T.maxRotDisP : T.maxRotDis) + (size_t)g.y * Nd : nullptr;      // (slot clouds of this kernel are stored in T.perm order)
+    const float* __restrict__ rho = g.y >= 0 ? rho_rows(T) + (size_t)g.y * Nd : nullptr;      // (slot clouds of this kernel are stored in T.perm order)
     if (tid < TC) {
         const int j = tid, c = min(base + j, n - 1);          // the tail tile re-evaluates the last cube
         const float x = cubes[4 * c], y = cubes[4 * c + 1], z = cubes[4 * c + 2], w = cubes[4 * c + 3];
@@ -248,7 +248,7 @@ __global__ __launch_bounds__(512, 4) void k_eval_cubes_geo(DevTables T, const fl
 #pragma unroll
     for (int m = 0; m < PPT; m++) { px[m] = py[m] = pz[m] = pw[m] = prho[m] = 0.f; }
     if constexpr (DUAL) {
-        sweep_tile<512, PPT, false, TC, true, true, XBIG, !XBIG>(T, sh, px, py, pz, pw, prho, false, xr, row, rot, nullptr, T.code ? lutl : nullptr, rho);
+        sweep_tile<512, PPT, false, TC, true, true, XBIG, !XBIG, NORM>(T, sh, px, py, pz, pw, prho, false, xr, row, rot, nullptr, T.code ? lutl : nullptr, rho);
         // (results out by lane id, from every wave alike -- identical values to identical addresses: the workitem id would have to survive the
         // whole sweep in a register the kernel does not have, i.e. in scratch)
         const int ol = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
@@ -257,7 +257,7 @@ __global__ __launch_bounds__(512, 4) void k_eval_cubes_geo(DevTables T, const fl
             ub_out[(size_t)g.w * n + base + ol] = sh.ub[ol];  lb_out[(size_t)g.w * n + base + ol] = sh.lb[ol];
         }
     } else {
-        sweep_tile<512, PPT, false, TC, true, false, XBIG, !XBIG>(T, sh, px, py, pz, pw, prho, g.y >= 0, xr, row, rot, rho, T.code ? lutl : nullptr);
+        sweep_tile<512, PPT, false, TC, true, false, XBIG, !XBIG, NORM>(T, sh, px, py, pz, pw, prho, g.y >= 0, xr, row, rot, rho, T.code ? lutl : nullptr);
         const int ol = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
         if (ol < TC && base + ol < n) { ub_out[(size_t)by * n + base + ol] = sh.ub[ol]; lb_out[(size_t)by * n + base + ol] = sh.lb[ol]; }
     }
@@ -335,8 +335,8 @@ int launch_eval(goicp_engine* h, int slot, int rot_level, const int2* groups_dev
         }
         const int ng = dual ? h->npairs : ngroups, xm = h->xcd_mode;
         const long long wgs = xm == 1 ? 8ll * (((long long)tiles * ng + 7) / 8) : (xm == 2 ? 8ll * ((tiles + 7) / 8) * ng : (long long)tiles * ng);
-#define CALLG(P2) do { if (dual) hipLaunchKernelGGL((k_eval_cubes_geo<P2, true>), dim3((unsigned)wgs), dim3(512), 0, h->stream, h->T, h->d_rot, gtab, (const float*)cubes_dev, n, (float*)ub_dev, (float*)lb_dev, tiles, ng, xm, 0); \
-                       else hipLaunchKernelGGL((k_eval_cubes_geo<P2, false>), dim3((unsigned)wgs), dim3(512), 0, h->stream, h->T, h->d_rot, gtab, (const float*)cubes_dev, n, (float*)ub_dev, (float*)lb_dev, tiles, ng, xm, 0); } while (0)
+#define CALLGN(P2, D, NRM) hipLaunchKernelGGL((k_eval_cubes_geo<P2, D, false, NRM>), dim3((unsigned)wgs), dim3(512), 0, h->stream, h->T, h->d_rot, gtab, (const float*)cubes_dev, n, (float*)ub_dev, (float*)lb_dev, tiles, ng, xm, 0)
+#define CALLG(P2) do { if (h->T.norm == 2) { if (dual) CALLGN(P2, true, 2); else CALLGN(P2, false, 2); } else { if (dual) CALLGN(P2, true, 0); else CALLGN(P2, false, 0); } } while (0)
         if (h->T.exact_big) {
             // parity_mode 2: every workgroup owns a slot of row scratch, so the launch goes out in chunks of T.xslots workgroups
             const long long total = (long long)tiles * ng;
@@ -349,6 +349,7 @@ int launch_eval(goicp_engine* h, int slot, int rot_level, const int2* groups_dev
             }
         } else if (h->ppt == 2) CALLG(4); else if (h->ppt == 4) CALLG(8); else CALLG(10);
 #undef CALLG
+#undef CALLGN
         HIPCHK(h, hipGetLastError());
         h->n_cubes += (uint64_t)n * ngroups; h->n_lookups += (uint64_t)n * ngroups * h->T.Nd;
         return GOICP_OK;

@@ -23,12 +23,13 @@ __global__ __launch_bounds__(256) void k_fr_init(DevTables T, FrCtx C) {
     const goicp_bnb_job jb = C.jobs[job];
     float4* srot = C.srot + (size_t)job * C.NdP;
     for (int i = tid; i < T.Nd; i += 256) {            // K5: pDataTemp = R*p, float, left to right (reference jly_goicp.cpp:750-756)
-        const float x = T.dxyz[3 * i], y = T.dxyz[3 * i + 1], z = T.dxyz[3 * i + 2];
+        const int s = src_point(T, i);
+        const float x = T.dxyz[3 * s], y = T.dxyz[3 * s + 1], z = T.dxyz[3 * s + 2];
         float4 p;
         p.x = jb.R[0] * x + jb.R[1] * y + jb.R[2] * z;
         p.y = jb.R[3] * x + jb.R[4] * y + jb.R[5] * z;
         p.z = jb.R[6] * x + jb.R[7] * y + jb.R[8] * z;
-        p.w = T.weights[i];
+        p.w = T.weights[s];
         srot[i] = p;
     }
     if (tid == 0) {
@@ -211,7 +212,7 @@ __device__ __forceinline__ void fr_expand_item(const DevTables& T, const FrCtx& 
     if (MODE == 0 && T.code) { for (int i = tid; i < LUT_LDS; i += BLOCK) lutl[i] = T.lut[i]; }   // (ordered by the barrier behind the cube set-up)
     const int level = C.jobs[item.job].rot_level;
     const float4* rot = C.srot + (size_t)item.job * C.NdP;
-    const float* rho = level >= 0 ? T.maxRotDis + (size_t)level * T.Nd : nullptr;
+    const float* rho = level >= 0 ? rho_rows(T) + (size_t)level * T.Nd : nullptr;
     const int j0 = MODE == 0 ? item.split * NT : 0;        // first child of this item
     if (tid < TC) {                                     // children of the node (reference jly_goicp.cpp:322-333)
         const int j = (tid < NT ? tid : 0) + j0;        // rows past NT repeat child j0 (sweep_tile reads the centre of row 4 for the second z value)
