@@ -496,13 +496,13 @@ struct TileShm {
 #define FW_SHIFT 17
 #define FW_KBASE ((int)(0x39800000u >> FW_SHIFT))        // key of 2^-12
 #define FW_HP_WORDS 512                                   // packed words per cube histogram
-template <int BLOCK>
+template <int BLOCK, bool H32>
 __device__ __forceinline__ void fw_hist_reset(TileShm<BLOCK>& sh) {   // every lane of the workgroup; a workgroup barrier must follow before the first add
     typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
     typedef __attribute__((address_space(3))) u32x4_t lds_u128;
     lds_u128* hp = (lds_u128*)&sh.hist[0][0];
     const u32x4_t z = {0u, 0u, 0u, 0u};
-    for (int k = threadIdx.x; k < TC * FW_HP_WORDS / 4; k += BLOCK) hp[k] = z;
+    for (int k = threadIdx.x; k < TC * (H32 ? 1024 : FW_HP_WORDS) / 4; k += BLOCK) hp[k] = z;   // (32-bit bins: the whole of sh.hist, no transposition scratch in that variant)
     if (threadIdx.x < TC) { sh.prefix[threadIdx.x] = 0u; sh.zc[threadIdx.x] = 0; sh.ncand[threadIdx.x] = 0; }
     if (threadIdx.x == 0) { sh.fallback = 0; sh.himask = 0u; }
 }
@@ -523,6 +523,10 @@ __device__ __forceinline__ void sweep_tile(const DevTables& T, TileShm<BLOCK>& s
                                            const float* __restrict__ dual_rho = nullptr) {
     const int tid = threadIdx.x;
     const int Nd = T.Nd;
+    // the two forms of the fast path (measured, 149 760 cube-evals per launch): a tile evaluated for ONE call spends most of its time gathering and gains
+    // from the transposed gathers (1.82 vs 1.93 ms), whose scratch takes half of sh.hist and leaves room for 16-bit bins only; a fused (no radius,
+    // radius) tile is selection-heavy and gains more from plain 32-bit bins -- a shift, a subtract, a clamp and one LDS add per value (1.21 vs 1.35 ms)
+    constexpr bool XPOSE = XP && !DUAL, H32 = XP && DUAL;
     float r[NT][PPT];
     // gathers: the NT lookups of one point are issued back to back (no consumer in between), so every lane keeps NT loads
     // in flight. A lookup that leaves the grid only sets a flag bit; its extension length (jly_3ddt.cpp:1150-1187) is
@@ -590,9 +594,15 @@ __device__ __forceinline__ void sweep_tile(const DevTables& T, TileShm<BLOCK>& s
         const bool nz = bits != 0u;
         fw_z[j] += __popcll(__ballot(!nz));            // (includes the lanes past Nd: BLOCK * PPT - Nd of them per cube, subtracted at the scan)
         int k = (int)(bits >> FW_SHIFT) - FW_KBASE;
-        fw_hi |= (__ballot(nz && k > 1023) ? 1u : 0u) << j;
-        k = min(max(k, 0), 1023);
-        if (nz) atomicAdd((unsigned*)((lds_u32*)&sh.hist[0][0] + j * FW_HP_WORDS + (k >> 1)), 1u << ((k & 1) * 16));
+        if constexpr (H32) {
+            // 32-bit bins: shift, subtract, clamp, one LDS add; residuals above the window simply land in bin 1023, which is never trusted (scan)
+            k = min(max(k, 0), 1023);
+            if (nz) atomicAdd((unsigned*)((lds_u32*)&sh.hist[0][0] + j * 1024 + k), 1u);
+        } else {
+            fw_hi |= (__ballot(nz && k > 1023) ? 1u : 0u) << j;
+            k = min(max(k, 0), 1023);
+            if (nz) atomicAdd((unsigned*)((lds_u32*)&sh.hist[0][0] + j * FW_HP_WORDS + (k >> 1)), 1u << ((k & 1) * 16));
+        }
     };
     auto fw_flush = [&]() __attribute__((always_inline)) {
         if ((tid & 63) == 0) {
@@ -636,8 +646,7 @@ __device__ __forceinline__ void sweep_tile(const DevTables& T, TileShm<BLOCK>& s
 #pragma unroll
             for (int j = 0; j < NT; j++) v[j] = dt_decode(T, idx[j], c[j], lut_lds);
         };
-#ifndef GOICP_NO_XP
-        if (XP && T.code) {
+        if (XPOSE && T.code) {
             static_assert(!XP || (NT == 8 && BLOCK / 64 <= TC), "transposed gathers: 8-cube tiles, one hist row per wave");
             typedef __attribute__((address_space(3))) unsigned lds_u32;
             typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
@@ -661,9 +670,7 @@ __device__ __forceinline__ void sweep_tile(const DevTables& T, TileShm<BLOCK>& s
             const u32x4_t ca = *(lds_u128*)(xs + p8), cb = *(lds_u128*)(xs + p8 + 4);
             c[0] = ca.x; c[1] = ca.y; c[2] = ca.z; c[3] = ca.w; c[4] = cb.x; c[5] = cb.y; c[6] = cb.z; c[7] = cb.w;
             decode_all(c);
-        } else
-#endif
-        if (T.code) {
+        } else if (T.code) {
             // coded grid: 2-byte gathers (half the cache lines of the float grid), then the value from the LUT
             unsigned c[NT];
 #pragma unroll
@@ -716,7 +723,7 @@ __device__ __forceinline__ void sweep_tile(const DevTables& T, TileShm<BLOCK>& s
         typedef __attribute__((address_space(3))) u32x4_t lds_u128;
         if (!have_hist) {
             __syncthreads();                          // (every wave is done with the bounds / flags of the previous selection)
-            fw_hist_reset(sh);
+            fw_hist_reset<BLOCK, H32>(sh);
             __syncthreads();
 #pragma unroll
             for (int m = 0; m < PPT; m++) {
@@ -728,11 +735,18 @@ __device__ __forceinline__ void sweep_tile(const DevTables& T, TileShm<BLOCK>& s
         __syncthreads();                                                            // all adds are in
         TSTAMP(2);
         for (int j = wv; j < NT; j += NW) {             // one wave scans the 1024 bins of a cube: 16 per lane = two 16-byte reads
+            unsigned c[16]; int mine = 0;
+            if constexpr (H32) {
+                const lds_u128* hp = (const lds_u128*)&sh.hist[0][0] + j * 256 + 4 * ln;
+                const u32x4_t w0 = hp[0], w1 = hp[1], w2 = hp[2], w3 = hp[3];
+                c[0] = w0.x; c[1] = w0.y; c[2] = w0.z; c[3] = w0.w; c[4] = w1.x; c[5] = w1.y; c[6] = w1.z; c[7] = w1.w;
+                c[8] = w2.x; c[9] = w2.y; c[10] = w2.z; c[11] = w2.w; c[12] = w3.x; c[13] = w3.y; c[14] = w3.z; c[15] = w3.w;
+            } else {
             const lds_u128* hp = (const lds_u128*)&sh.hist[0][0] + j * (FW_HP_WORDS / 4) + 2 * ln;
             const u32x4_t wa = hp[0], wb = hp[1];
-            unsigned c[16]; int mine = 0;
             c[0] = wa.x & 0xFFFFu; c[1] = wa.x >> 16; c[2] = wa.y & 0xFFFFu; c[3] = wa.y >> 16; c[4] = wa.z & 0xFFFFu; c[5] = wa.z >> 16; c[6] = wa.w & 0xFFFFu; c[7] = wa.w >> 16;
             c[8] = wb.x & 0xFFFFu; c[9] = wb.x >> 16; c[10] = wb.y & 0xFFFFu; c[11] = wb.y >> 16; c[12] = wb.z & 0xFFFFu; c[13] = wb.z >> 16; c[14] = wb.w & 0xFFFFu; c[15] = wb.w >> 16;
+            }
 #pragma unroll
             for (int q = 0; q < 16; q++) mine += (int)c[q];
             int incl = mine;
@@ -758,7 +772,7 @@ __device__ __forceinline__ void sweep_tile(const DevTables& T, TileShm<BLOCK>& s
                 const int bin = 16 * ln + b;
                 // threshold below the window (bin 0 also holds everything under 2^-12), above it (bin 1023 holds everything from 2^4 on), or in a
                 // crowded bin: the generic byte passes decide
-                if (bin == 0 || (bin == 1023 && ((sh.himask >> j) & 1u)) || cb > CAND_CAP) sh.fallback = 1;
+                if (bin == 0 || (bin == 1023 && (H32 || ((sh.himask >> j) & 1u))) || cb > CAND_CAP) sh.fallback = 1;
                 sh.prefix[j] = (unsigned)(FW_KBASE + bin) << FW_SHIFT;
                 sh.rem[j] = rr;                               // rank among the members of the threshold bin
             }

@@ -238,7 +238,7 @@ __global__ __launch_bounds__(512, 4) void k_eval_cubes_geo(DevTables T, const fl
         sh.cen[j][0] = x + w / 2; sh.cen[j][1] = y + w / 2; sh.cen[j][2] = z + w / 2;
         sh.mtd[j] = (float)(SQRT3_D / 2.0 * w);
     }
-    if (!XBIG && T.doTrim) fw_hist_reset(sh);           // the first selection's histogram is filled beside the gathers (sweep_tile<..., XP>)
+    if (!XBIG && T.doTrim) fw_hist_reset<512, DUAL>(sh);           // the first selection's histogram is filled beside the gathers (sweep_tile<..., XP>)
     __syncthreads();
     // every lane decides for itself whether the tile is a row of x-neighbours (broadcast LDS reads, no second barrier)
     bool row = true;
