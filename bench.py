@@ -253,6 +253,9 @@ def main():
                                   note="dt_mode=1: exact Euclidean transform built on the GPU (not bit-identical to the reference's propagated grid; opt-in)"))
         if args.overlap_pairs > 1:
             reg.update(overlapped_registrations(goicp_amd, synth_pair, cfg, nd, args.overlap_pairs, local, world, rank, use_dist, dist, dev, torch))
+            # the same with the device-built grid: 4 x as many pairs, the same number of registrations in flight
+            reg["device_dt"].update(overlapped_registrations(goicp_amd, synth_pair, cfg, nd, 4 * args.overlap_pairs, local, world, rank, use_dist, dist, dev, torch,
+                                                             dt_mode=1, threads=args.overlap_pairs, tag="in_flight"))
 
     # ---- BASELINE configs[3]: the cavity batch under the c-FPFH weighted error, through the batch driver -------------
     cav = None
@@ -366,28 +369,29 @@ def stress_leg(goicp_amd, synth_pair, local, torch, dev, steps):
                          "issued_bytes_per_launch": issued, "fused_group_pairs": fused}}
 
 
-def overlapped_registrations(goicp_amd, synth_pair, cfg, nd, n_pairs, local, world, rank, use_dist, dist, dev, torch):
-    """pairs/s including the DT build when the builds (host) of some pairs overlap the registrations (GPU) of others:
-    n_pairs configs[2]-shaped pairs per rank on n_pairs host threads, each BuildDT() -> Register()."""
+def overlapped_registrations(goicp_amd, synth_pair, cfg, nd, n_pairs, local, world, rank, use_dist, dist, dev, torch, dt_mode=0, threads=None, tag="overlapped"):
+    """pairs/s including the DT build when several registrations are in flight on one GPU: n_pairs configs[2]-shaped pairs per rank on host
+    threads, each BuildDT() -> Register() (SURVEY.md 8(f) row 1). dt_mode 0: the host builder's 0.9 s overlap the other pairs' GPU work;
+    dt_mode 1: the grid is built on the device in milliseconds and the registrations' own launch gaps (search rounds, ICP iterations) overlap."""
     from concurrent.futures import ThreadPoolExecutor
     pairs = [synth_pair(nd, seed=20260201 + 17 * (rank * n_pairs + k), theta_range=(2.2, 3.1)) for k in range(n_pairs)]
 
     def one(Pk):
-        gk = goicp_amd.GoICP(cfg, device_id=local); gk.set_clouds(Pk["t"], Pk["s"])
+        gk = goicp_amd.GoICP(cfg, device_id=local, dt_mode=dt_mode); gk.set_clouds(Pk["t"], Pk["s"])
         t0 = time.perf_counter(); gk.build_dt(); t1 = time.perf_counter(); o = gk.register(); t2 = time.perf_counter()
         gk.close()
         return t1 - t0, t2 - t1, float(np.abs(o["R"] - Pk["Rtrue"]).max())
     if use_dist:
         dist.barrier()
     t0 = time.perf_counter()
-    with ThreadPoolExecutor(max_workers=n_pairs) as ex:
+    with ThreadPoolExecutor(max_workers=threads or n_pairs) as ex:
         outs = list(ex.map(one, pairs))
     t = time.perf_counter() - t0
     if use_dist:
         tt = torch.tensor([t], dtype=torch.float64, device=dev); dist.all_reduce(tt, op=dist.ReduceOp.MAX); t = float(tt.item())
-    return dict(overlapped_pairs=n_pairs * world, overlapped_seconds=t, pair_registrations_per_sec_incl_dt_build_overlapped=n_pairs * world / t,
-                overlapped_mean_dt_build_seconds=float(np.mean([o[0] for o in outs])), overlapped_mean_register_seconds=float(np.mean([o[1] for o in outs])),
-                overlapped_max_dR_vs_planted=float(max(o[2] for o in outs)))
+    return {tag + "_pairs": n_pairs * world, tag + "_seconds": t, "pair_registrations_per_sec_incl_dt_build_" + tag: n_pairs * world / t,
+            tag + "_mean_dt_build_seconds": float(np.mean([o[0] for o in outs])), tag + "_mean_register_seconds": float(np.mean([o[1] for o in outs])),
+            tag + "_max_dR_vs_planted": float(max(o[2] for o in outs))}
 
 
 def cavity_batch(goicp_amd, args, rank, world, local, use_dist, dist, dev, torch):

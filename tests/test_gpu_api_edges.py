@@ -8,7 +8,7 @@ import pytest
 
 import goicp_amd
 from goicp_amd.binding import BnbJob, BnbResult
-from helpers import load_clouds, load_hotpath
+from helpers import GOLDEN, load_clouds, load_hotpath, synth_pair
 from test_gpu_parity import engine_from_hotpath
 
 pytestmark = pytest.mark.gpu
@@ -230,3 +230,25 @@ def test_concurrent_engines_of_different_sizes_share_kernel_instantiations():
         for a, b in zip(seq, outs):
             assert a["error"] == b["error"] and np.array_equal(a["R"], b["R"]) and np.array_equal(a["t"], b["t"])
             assert a["stats"]["trans_pops"] == b["stats"]["trans_pops"]
+
+
+def test_register_budgets_return_the_best_pose_so_far():
+    """GoICP::wall_budget_s / search_pop_budget (goicp_set_budget): a search that cannot run to convergence returns the incumbent with budget_hit set
+    and status OK; without budgets the same pair converges to the reference's known answer (tests/golden/c3_reference.json)."""
+    import json
+    G = json.load(open(os.path.join(GOLDEN, "c3_reference.json")))
+    P = synth_pair(5000, seed=20260101, theta_range=(2.2, 3.1))
+    v = goicp_amd.cfg_vector(**G["cfg"])
+    g = goicp_amd.GoICP(v, dt_mode=1); g.set_clouds(P["t"], P["s"]); g.build_dt()
+    g.set_budget(0.0, 50)                       # 50 translation-queue pops per InnerBnB call: the first search already needs more
+    out = g.register()
+    assert out["budget_hit"] and np.isfinite(out["error"]) and out["error"] > G["error"] * 1.5
+    assert [a for a, _ in out["trace"]][:2] == ["Init", "ICP"] and out["stats"]["trans_pops"] >= 50
+    g.set_budget(1e-6, 0)                       # wall budget: checked before every rotation-queue pop
+    out = g.register()
+    assert out["budget_hit"] and out["stats"]["rot_pops"] <= 1
+    g.set_budget(0.0, 0)
+    out = g.register()
+    assert not out["budget_hit"] and abs(float(out["error"]) - G["error"]) <= 1e-5 * G["error"] and out["stats"]["trans_pops"] == G["pops"]
+    assert out["search"]["rounds"] > 0 and out["search"]["cube_evals_launched"] >= out["stats"]["cube_evals"]
+    g.close()
