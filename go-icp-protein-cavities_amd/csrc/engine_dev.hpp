@@ -60,6 +60,7 @@ struct DevTables {
     float4* srot;            // streaming path (Nd > 8192): per-workgroup rotated cloud [NdP]
     float* srows;            // streaming path, trimmed runs: per-workgroup residual rows [TC][NdP]
     int NdP;                 // row pitch of the two above
+    int regsel;              // reference-order selection (trimmed parity runs): partition rounds on ranges of <= 64 elements run in registers, one element per lane
     int dbg;                 // GOICP_DBG ablation bits (diagnosis only; results are wrong when set)
     unsigned long long* dbg_times;   // [8] per-phase cycle sums of job 0, lane 0 (GOICP_DBG & 32)
 };
@@ -252,7 +253,7 @@ __device__ __forceinline__ int wave_median_of_medians(float* d, int* idx, int s,
 }
 template <bool MEM = false>
 __device__ __forceinline__ void wave_intro_select(float* d, int* idx, int n, int k, int lane, unsigned long long* st = nullptr /* diagnosis: [0] rows [1] rounds [2] median-of-medians rounds [3] cycles in them [4] cycles in the final insertion sort */,
-                                                  bool regsel = false /* experimental (GOICP_DBG bit 256): ranges of <= 64 elements finish in registers, one element per lane (tests/csrc/partition_check.c, reg()) */) {
+                                                  bool regsel = false /* ranges of <= 64 elements finish in registers, one element per lane (tests/csrc/partition_check.c, reg()); default on (T.regsel), GOICP_REGSEL=0 switches it off */) {
     int s = 0, e = n - 1;
     int prev = e - s + 1, tries = 0; bool quick = true;
     unsigned long long n_rounds = 0, n_mom = 0, c_mom = 0, c_ins = 0, c_a = 0, c_b = 0, c_c = 0, c_d = 0, tq = 0;
@@ -938,7 +939,7 @@ __device__ __forceinline__ void sweep_tile(const DevTables& T, TileShm<BLOCK>& s
         }
         __syncthreads();
         for (int j = tid >> 6; j < NT; j += BLOCK / 64)
-            wave_intro_select<JIT>(rbuf + j * Nd, reinterpret_cast<int*>(rbuf + NT * Nd) + j * Nd, Nd, T.inlierNum - 1, tid & 63, DBG_ON(T, 32) && T.dbg_times ? T.dbg_times + 8 : nullptr, (T.dbg & 256) != 0);      // (JIT: rows in HBM)
+            wave_intro_select<JIT>(rbuf + j * Nd, reinterpret_cast<int*>(rbuf + NT * Nd) + j * Nd, Nd, T.inlierNum - 1, tid & 63, DBG_ON(T, 32) && T.dbg_times ? T.dbg_times + 8 : nullptr, T.regsel != 0);      // (JIT: rows in HBM)
         __syncthreads();
         if (tid < 2 * NT) {
             const int j = tid & (NT - 1);
