@@ -221,6 +221,12 @@ def main():
     if rank == 0 and default_shape_run and not args.no_stress:
         stress = stress_leg(goicp_amd, synth_pair, local, torch, dev, args.stress_steps)
 
+    # ---- BASELINE configs[3]: the cavity batch under the c-FPFH weighted error, through the batch driver. Before the registration legs: on some boxes
+    #      the device runs its latency-bound kernels up to 1.5x slower after several seconds of sustained load (batch 241 pairs/s behind them, 360-500 ahead) ----
+    cav = None
+    if not args.no_register and args.cavity_rows > 0:
+        cav = cavity_batch(goicp_amd, args, rank, world, local, use_dist, dist, dev, torch)
+
     # ---- end-to-end registration of the same pair ------------------------------------------------------
     reg = None
     if not args.no_register:
@@ -256,11 +262,6 @@ def main():
             # the same with the device-built grid: 4 x as many pairs, the same number of registrations in flight
             reg["device_dt"].update(overlapped_registrations(goicp_amd, synth_pair, cfg, nd, 4 * args.overlap_pairs, local, world, rank, use_dist, dist, dev, torch,
                                                              dt_mode=1, threads=args.overlap_pairs, tag="in_flight"))
-
-    # ---- BASELINE configs[3]: the cavity batch under the c-FPFH weighted error, through the batch driver -------------
-    cav = None
-    if not args.no_register and args.cavity_rows > 0:
-        cav = cavity_batch(goicp_amd, args, rank, world, local, use_dist, dist, dev, torch)
 
     # ---- CPU baseline: the unmodified reference (oracle/_ref) replaying the same InnerBnB calls, bounded -------
     cpu = None

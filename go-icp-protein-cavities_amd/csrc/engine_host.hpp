@@ -32,7 +32,7 @@ struct goicp_engine {
     int jit_bnb;                             // geometric searches of 1025..2048 points: k_inner_bnb<512, 4, false, false, true>
     // round-based search (k_fr_*): geometric searches of more than 1024 points
     int fr_mode;                             // 0 off, else 1 + MODE of k_fr_expand
-    int fr_ppt, fr_block, fr_nsplit, fr_wgs, fr_heap_cap, fr_depth2;
+    int fr_ppt, fr_block, fr_nsplit, fr_wgs, fr_heap_cap, fr_depth2, fr_kmax;
     FrState* fr_st; HeapNodeX* fr_heaps; FrExp* fr_exps; FrItem* fr_wl; unsigned* fr_cnt; double* fr_parts; float4* fr_srot; goicp_bnb_result* fr_results;
     size_t fr_jobs, fr_cap_nodes, fr_cap_exps; int fr_wl_cap;
     uint64_t fr_rounds, fr_spec_cubes, n_regrow;

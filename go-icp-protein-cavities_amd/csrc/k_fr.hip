@@ -266,7 +266,7 @@ __global__ __launch_bounds__(BLOCK, (MODE == 0 ? 4 : (BLOCK == 512 ? 4 : 1))) vo
 
 
 // ---- round-based search: buffers, launch loop ------------------------------------------------------------------
-#define FR_KMAX 16
+#define FR_KMAX 63          // upper limit of the nodes a search may have expanded per round (k_fr_select looks at the first 63 queue slots); the engine's own limit is h->fr_kmax
 #define FR_ROUNDS_MAX 64
 static int ensure_fr(goicp_engine* h, size_t jobs, size_t cap, size_t ecap) {
     // per-search arrays (state, results, rotated cloud, work list) grow with the number of searches; the queue and expansion slabs
@@ -275,7 +275,7 @@ static int ensure_fr(goicp_engine* h, size_t jobs, size_t cap, size_t ecap) {
         HIPCHK(h, hipStreamSynchronize(h->stream));
         { void* fr[] = {h->fr_st, h->fr_wl, h->fr_srot, h->fr_results}; for (void* p : fr) if (p) cache_free(p); }
         h->fr_st = nullptr; h->fr_wl = nullptr; h->fr_srot = nullptr; h->fr_results = nullptr; h->fr_jobs = 0;
-        const size_t wl_cap = std::min<size_t>(jobs * FR_KMAX * 9 * (size_t)h->fr_nsplit * 2, (size_t)1 << 26);
+        const size_t wl_cap = std::min<size_t>(jobs * (size_t)h->fr_kmax * 9 * (size_t)h->fr_nsplit * 2, (size_t)1 << 26);
         HIPCHK(h, cache_malloc((void**)&h->fr_st, jobs * sizeof(FrState), h->device));
         HIPCHK(h, cache_malloc((void**)&h->fr_results, jobs * sizeof(goicp_bnb_result), h->device));
         HIPCHK(h, cache_malloc((void**)&h->fr_wl, wl_cap * sizeof(FrItem), h->device));
@@ -345,7 +345,7 @@ int run_fr(goicp_engine* h, const goicp_bnb_job* jobs, int njobs, goicp_bnb_resu
         // (measured on the 16 searches of a configs[2] rotation pop: one level 9.3 ms / 184 rounds, two levels 11.9 ms / 120 rounds)
         int depth = ((long long)active * 9 * per_tile * 8 <= target && h->fr_depth2) ? 2 : 1;
         const int slots = depth == 2 ? 9 : 1;
-        const int K = std::max(1, std::min(FR_KMAX, target / (int)std::max(1ll, (long long)active * slots * per_tile)));
+        const int K = std::max(1, std::min(h->fr_kmax, target / (int)std::max(1ll, (long long)active * slots * per_tile)));
         HIPCHK(h, hipMemsetAsync(h->fr_cnt, 0, 2 * FR_ROUNDS_MAX * sizeof(unsigned), h->stream));
         for (int r = 0; r < rounds; r++) {
             hipLaunchKernelGGL(k_fr_select, dim3(njobs), dim3(FR_SELECT_THREADS), 0, h->stream, C, r, K, depth);
