@@ -215,14 +215,14 @@ def main():
             del os.environ["GOICP_FUSE"]
 
     # ---- BASELINE configs[4] shape: 50 000 points, 500^3 grid (beyond the Infinity Cache), untrimmed: the HBM-bound sweep. Right behind the metric
-    #      leg (same device state: after the registration and batch legs the same launches measured 1.5x slower on a box, 29.8 vs 19.1-19.6 ms) -------
+    #      leg (behind the registration and batch legs the same launches once measured 29.8 ms instead of 19.1-19.6) -------
     stress = None
     default_shape_run = nd == N_POINTS and args.dt == DT_SIZE and abs(args.trim - TRIM) < 1e-9
     if rank == 0 and default_shape_run and not args.no_stress:
         stress = stress_leg(goicp_amd, synth_pair, local, torch, dev, args.stress_steps)
 
-    # ---- BASELINE configs[3]: the cavity batch under the c-FPFH weighted error, through the batch driver. Before the registration legs: on some boxes
-    #      the device runs its latency-bound kernels up to 1.5x slower after several seconds of sustained load (batch 241 pairs/s behind them, 360-500 ahead) ----
+    # ---- BASELINE configs[3]: the cavity batch under the c-FPFH weighted error, through the batch driver (ahead of the registration legs; its rate follows
+    #      the host cores the box has free: 241-557 pairs/s over this round's runs of the same build, tools/order_effect.py) ----
     cav = None
     if not args.no_register and args.cavity_rows > 0:
         cav = cavity_batch(goicp_amd, args, rank, world, local, use_dist, dist, dev, torch)

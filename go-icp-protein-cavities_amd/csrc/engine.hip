@@ -792,7 +792,7 @@ extern "C" int goicp_engine_create(const goicp_engine_desc* d, goicp_engine** ou
             CR(bnb_configure(h, ncu));                 // sets h->resident_jobs
             // searches of more than 1024 points without penalty terms run round by round over many workgroups (k_fr_*)
             h->fr_mode = 0; h->fr_nsplit = 1; h->fr_ppt = 4; h->fr_block = 512; h->fr_wgs = 2 * std::max(1, ncu); h->fr_heap_cap = 8192;
-            h->fr_kmax = 16; { const char* e = getenv("GOICP_FR_KMAX"); if (e && atoi(e) >= 1 && atoi(e) <= 63) h->fr_kmax = atoi(e); }
+            h->fr_kmax = 32; { const char* e = getenv("GOICP_FR_KMAX"); if (e && atoi(e) >= 1 && atoi(e) <= 63) h->fr_kmax = atoi(e); }
             h->fr_depth2 = (getenv("GOICP_FR_DEPTH") && atoi(getenv("GOICP_FR_DEPTH")) == 2) ? 1 : 0;   // two-level expansion: measured slower on configs[2] (more sweeps per round than rounds saved); knob kept for deep searches
             const bool fr_off = getenv("GOICP_FR") && atoi(getenv("GOICP_FR")) == 0;          // A/B knob, read once per engine
             if ((!fr_off || T.exact_big || T.exact_stream) && !T.exact && !T.use_compat && !T.use_fpfh && d->Nd > 1024) {
