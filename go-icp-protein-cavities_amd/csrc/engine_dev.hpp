@@ -723,9 +723,7 @@ __device__ __forceinline__ void sweep_tile(const DevTables& T, TileShm<BLOCK>& s
         typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
         typedef __attribute__((address_space(3))) u32x4_t lds_u128;
         if (!have_hist) {
-            __syncthreads();                          // (every wave is done with the bounds / flags of the previous selection)
-            fw_hist_reset<BLOCK, H32>(sh);
-            __syncthreads();
+            __syncthreads();                          // (the histograms were cleared by the caller, behind the previous selection's last barrier: fw_hist_reset)
 #pragma unroll
             for (int m = 0; m < PPT; m++) {
 #pragma unroll
@@ -1250,6 +1248,9 @@ __device__ __forceinline__ void sweep_tile(const DevTables& T, TileShm<BLOCK>& s
     if constexpr (DUAL) {
         // (two call sites rather than a loop: inside a loop the compiler hoists the block's lane-constant addresses and spills the residuals)
         if (tid < NT) { sh.ub2[tid] = sh.ub[tid]; sh.lb2[tid] = sh.lb[tid]; }        // (ordered by the barriers of the next finish())
+        // the second selection's histograms are cleared here, beside the radius fetches below: every wave has left the first selection (its last
+        // phase ends with a workgroup barrier), nothing reads the histograms or the per-cube counters any more
+        if constexpr (XP) { if (T.doTrim) fw_hist_reset<BLOCK, H32>(sh); }
         // second bound of the same cubes: minDis -= maxRotDisL; clamp (reference jly_goicp.cpp:375-381) on the products weights*DT kept in r
         int tid2 = tid;
         asm volatile("" : "+v"(tid2));                     // (keeps the radius fetches below the first finish(): hoisted above it they cost PPT registers)
