@@ -36,7 +36,7 @@ DT_SIZE = 300
 TRIM = 0.1
 N_ROT = 16
 PEAK_HBM_GBPS = 8000.0          # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
-TILE_CUBES = 8                  # cubes that share one register-resident copy of the cloud (TC in engine.hip)
+TILE_CUBES = 8                  # cubes that share one register-resident copy of the cloud (TC in csrc/engine_dev.hpp)
 PMC_SUMMARY = os.path.join("profiles", "r03_summary.json")     # written by tools/profile_round.sh from rocprofv3 --pmc passes of this command
 PMC_SUMMARY_STRESS = os.path.join("profiles", "r03_c5_summary.json")   # the same for the configs[4]-shaped launch (python bench.py --points 50000 --dt 500 --trim 0)
 

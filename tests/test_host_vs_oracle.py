@@ -95,7 +95,7 @@ def test_protein_transform_reproduces_shipped_file(tmp_path):
 
 
 def test_parallel_partition_formulation_equals_the_sequential_loop(tmp_path):
-    """wave_intro_select (engine.hip) computes the reference's partition (jly_sorting.hpp:282-303) from ranks instead of a
+    """wave_intro_select (csrc/engine_dev.hpp) computes the reference's partition (jly_sorting.hpp:282-303) from ranks instead of a
     cell-by-cell scan; tests/csrc/partition_check.c checks that formulation against the sequential loop on random rows."""
     import subprocess
     exe = str(tmp_path / "partition_check")
