@@ -158,7 +158,9 @@ private:
     std::vector<float> normData_, minDis_;
     std::vector<int32_t> icp_id_data_, icp_id_model_, opt_id_data_, opt_id_model_;
     std::vector<double> icp_dis_;
-    std::vector<uint32_t> sort_key_, sort_a_, sort_b_;
+    std::vector<uint64_t> sort_a_, sort_b_;                    // ICP3D's points as packed (distance bits, data index) words
+    std::vector<double> icp_pm_, icp_pd_;                      // the matched model / transformed data points of one ICP iteration
+    std::vector<float> mxyz_, dxyz_;                           // packed coordinates of the clouds (set by Initialize)
     bool host_compat_ = false;             // geometric runs on a host-built grid: the compatibility count is taken on the host (no cell tables on the device)
     KdOrder kd_order_;                     // the reference kd-tree's visiting order, built on the first exact distance tie
     float OuterBnB();                      // reference jly_goicp.cpp:582-876

@@ -302,7 +302,8 @@ void GoICP::Initialize() {
     SSEThresh = MSEThresh * inlierNum;
 
     // ---- stage everything the hot path reads into HBM (once per registration)
-    std::vector<float> mxyz((size_t)3 * Nm), dxyz((size_t)3 * Nd), mf, df;
+    std::vector<float>& mxyz = mxyz_; std::vector<float>& dxyz = dxyz_; std::vector<float> mf, df;      // the coordinate tables stay for the ICP loop
+    mxyz.resize((size_t)3 * Nm); dxyz.resize((size_t)3 * Nd);
     std::vector<int32_t> mcol(Nm), dcol(Nd);
     for (int i = 0; i < Nm; i++) { mxyz[3 * i] = pModel[i].x; mxyz[3 * i + 1] = pModel[i].y; mxyz[3 * i + 2] = pModel[i].z; mcol[i] = pModel[i].c; }
     for (int i = 0; i < Nd; i++) { dxyz[3 * i] = pData[i].x; dxyz[3 * i + 1] = pData[i].y; dxyz[3 * i + 2] = pData[i].z; dcol[i] = pData[i].c; }
@@ -388,10 +389,14 @@ float GoICP::icp_run(Matrix& R, Matrix& t) {
     const float err_diff = MSEThresh / 10000;      // jly_goicp.cpp:232
     int num;
     if (doTrim) num = (int)(n * (1 - trimFraction)); else num = n;
-    struct Ref { double dis; int id_data, id_model; };
-    std::vector<Ref> pts(n), tmp(n);
+    // icp3d.points as packed (squared distance bits << 32 | data index) words: a non-negative float orders like its bit pattern, so the
+    // numeric order of the words is the order (dis, id_data) -- the order glibc's stable merge sort leaves under the reference's comparator
+    std::vector<uint64_t>& ka = sort_a_; std::vector<uint64_t>& kb = sort_b_;
+    ka.resize(n); kb.resize(n);
     std::vector<int32_t> ids(n), tied(n); std::vector<float> dsq(n);
-    std::vector<double> p_m((size_t)3 * std::max(num, 1)), p_d((size_t)3 * std::max(num, 1));
+    icp_pm_.resize((size_t)3 * std::max(num, 1)); icp_pd_.resize((size_t)3 * std::max(num, 1));
+    double* const p_m = icp_pm_.data(); double* const p_d = icp_pd_.data();
+    const float* const mx = mxyz_.data(); const float* const dx = dxyz_.data();
     double mu_m[3] = {0, 0, 0}, mu_d[3] = {0, 0, 0};
     double Rd[9], td[3];
     for (int i = 0; i < 3; i++) { for (int j = 0; j < 3; j++) Rd[3 * i + j] = R.val[i][j]; td[i] = t.val[i][0]; }
@@ -399,6 +404,9 @@ float GoICP::icp_run(Matrix& R, Matrix& t) {
     stats.icp_calls++;
     size_t iter = 0;
     bool finished = false;
+    auto pack_in_index_order = [&]() {
+        for (int i = 0; i < n; i++) { uint32_t k; std::memcpy(&k, &dsq[i], 4); ka[i] = ((uint64_t)k << 32) | (uint32_t)i; }
+    };
     if (!doTrim && device_icp) {
         // cavity-sized untrimmed clouds: the whole loop in one launch (k_icp_loop: same sums in the same order, same 3x3 algebra). It hands
         // back early only at an iteration with an exact distance tie between model points, which the kd-tree order below decides.
@@ -412,10 +420,7 @@ float GoICP::icp_run(Matrix& R, Matrix& t) {
             std::memcpy(Rd, S.R, sizeof Rd); std::memcpy(td, S.t, sizeof td);
             for (int k = 0; k < 3; k++) { mu_m[k] = S.mu_m[k]; mu_d[k] = S.mu_d[k]; }
             err = S.err; err_new = S.err_new;
-            if (S.status != 1) {
-                for (int i = 0; i < n; i++) { pts[i].dis = dsq[i]; pts[i].id_data = i; pts[i].id_model = ids[i]; }
-                finished = true;
-            }
+            if (S.status != 1) { pack_in_index_order(); finished = true; }
         } else if (rc != GOICP_ERR_ARG) { status = rc; return std::numeric_limits<float>::quiet_NaN(); }
     }
     for (; !finished && iter < 10000; iter++) {
@@ -427,58 +432,71 @@ float GoICP::icp_run(Matrix& R, Matrix& t) {
         for (int i = 0; i < n; i++) if (tied[i] > 1) {
             // several model points at exactly this distance: the reference's kd-tree keeps the first one it visits
             // (nanoflann.hpp:1147), so ask the restated tree which one that is
-            if (!kd_order_.built()) {
-                std::vector<float> mx((size_t)3 * Nm);
-                for (int m = 0; m < Nm; m++) { mx[3 * m] = pModel[m].x; mx[3 * m + 1] = pModel[m].y; mx[3 * m + 2] = pModel[m].z; }
-                kd_order_.build(mx.data(), Nm);
-            }
-            const float dx = pData[i].x, dy = pData[i].y, dz = pData[i].z;
-            const float q[3] = {r00 * dx + r01 * dy + r02 * dz + t0, r10 * dx + r11 * dy + r12 * dz + t1, r20 * dx + r21 * dy + r22 * dz + t2};   // jly_icp3d.hpp:239-241
+            if (!kd_order_.built()) kd_order_.build(mx, Nm);
+            const float x = dx[3 * i], y = dx[3 * i + 1], z = dx[3 * i + 2];
+            const float q[3] = {r00 * x + r01 * y + r02 * z + t0, r10 * x + r11 * y + r12 * z + t1, r20 * x + r21 * y + r22 * z + t2};   // jly_icp3d.hpp:239-241
             ids[i] = kd_order_.nearest(q);
         }
-        err_new = 0;
-        for (int i = 0; i < n; i++) { pts[i].dis = dsq[i]; pts[i].id_data = i; pts[i].id_model = ids[i]; }
-        if (doTrim) {
-            // qsort with a comparator that never reports equality (jly_icp3d.hpp:172-176,254); under glibc's merge
-            // sort ties keep their order, i.e. a stable sort by dis. dis is a non-negative float, so its bit pattern
-            // orders like the value: three stable counting passes (11+11+10 bits) give the same permutation.
-            std::vector<uint32_t>& key = sort_key_; std::vector<uint32_t>& ia = sort_a_; std::vector<uint32_t>& ib = sort_b_;
-            key.resize(n); ia.resize(n); ib.resize(n);
-            for (int i = 0; i < n; i++) { std::memcpy(&key[i], &dsq[i], 4); ia[i] = (uint32_t)i; }
-            uint32_t cnt[2048];
-            const int shifts[3] = {0, 11, 22}, bits[3] = {11, 11, 10};
-            for (int pass = 0; pass < 3; pass++) {
-                const uint32_t mask = (1u << bits[pass]) - 1u;
-                std::memset(cnt, 0, sizeof cnt);
-                for (int i = 0; i < n; i++) cnt[(key[ia[i]] >> shifts[pass]) & mask]++;
-                uint32_t run = 0;
-                for (uint32_t b = 0; b <= mask; b++) { const uint32_t c = cnt[b]; cnt[b] = run; run += c; }
-                for (int i = 0; i < n; i++) { const uint32_t id = ia[i]; ib[cnt[(key[id] >> shifts[pass]) & mask]++] = id; }
-                ia.swap(ib);
+        if (!doTrim) pack_in_index_order();
+        else {
+            // qsort with a comparator that never reports equality (jly_icp3d.hpp:172-176,254); under glibc's merge sort ties keep
+            // their order, i.e. a stable sort by dis = the numeric order of the packed words (unique, so any sorting method gives it).
+            // Two stable counting passes over key bits 10-20 and 21-31 (one read builds both histograms), then an insertion pass on the
+            // whole words for the low 10 key bits: runs of equal upper bits are short, and exact ties are already in index order. A cloud
+            // that defeats this (thousands of distinct distances inside one 2^-13 relative band) goes to std::sort after 16 n moves.
+            uint32_t cnt[2][2048];
+            std::memset(cnt, 0, sizeof cnt);
+            for (int i = 0; i < n; i++) {
+                uint32_t k; std::memcpy(&k, &dsq[i], 4);
+                ka[i] = ((uint64_t)k << 32) | (uint32_t)i; cnt[0][(k >> 10) & 2047u]++; cnt[1][k >> 21]++;
             }
-            for (int i = 0; i < n; i++) { const int id = (int)ia[i]; tmp[i].dis = dsq[id]; tmp[i].id_data = id; tmp[i].id_model = ids[id]; }
-            pts.swap(tmp);
+            for (int p = 0; p < 2; p++) {
+                uint32_t run = 0;
+                for (int b = 0; b < 2048; b++) { const uint32_t c = cnt[p][b]; cnt[p][b] = run; run += c; }
+                const int sh = 42 + 11 * p;
+                for (int i = 0; i < n; i++) { const uint64_t v = ka[i]; kb[cnt[p][(uint32_t)(v >> sh) & 2047u]++] = v; }
+                ka.swap(kb);
+            }
+            long moves = 0; const long budget = 16L * n;
+            int i = 1;
+            for (; i < n && moves <= budget; i++) {
+                const uint64_t v = ka[i]; int j = i - 1;
+                while (j >= 0 && ka[j] > v) { ka[j + 1] = ka[j]; j--; }
+                ka[j + 1] = v; moves += i - 1 - j;
+            }
+            if (i < n) std::sort(ka.begin(), ka.end());
         }
+        err_new = 0;
         for (int i = 0; i < num; i++) {
-            const int im = pts[i].id_model, id = pts[i].id_data;
-            p_m[3 * i] = pModel[im].x; mu_m[0] += p_m[3 * i];
-            p_m[3 * i + 1] = pModel[im].y; mu_m[1] += p_m[3 * i + 1];
-            p_m[3 * i + 2] = pModel[im].z; mu_m[2] += p_m[3 * i + 2];
-            const float dx = pData[id].x, dy = pData[id].y, dz = pData[id].z;
-            p_d[3 * i] = r00 * dx + r01 * dy + r02 * dz + t0; mu_d[0] += p_d[3 * i];
-            p_d[3 * i + 1] = r10 * dx + r11 * dy + r12 * dz + t1; mu_d[1] += p_d[3 * i + 1];
-            p_d[3 * i + 2] = r20 * dx + r21 * dy + r22 * dz + t2; mu_d[2] += p_d[3 * i + 2];
-            err_new = (float)(err_new + pts[i].dis);
+            const uint64_t v = ka[i];
+            const int id = (int)(uint32_t)v, im = ids[id];
+            const uint32_t kbits = (uint32_t)(v >> 32); float dis; std::memcpy(&dis, &kbits, 4);
+            p_m[3 * i] = mx[3 * im]; mu_m[0] += p_m[3 * i];
+            p_m[3 * i + 1] = mx[3 * im + 1]; mu_m[1] += p_m[3 * i + 1];
+            p_m[3 * i + 2] = mx[3 * im + 2]; mu_m[2] += p_m[3 * i + 2];
+            const float x = dx[3 * id], y = dx[3 * id + 1], z = dx[3 * id + 2];
+            p_d[3 * i] = r00 * x + r01 * y + r02 * z + t0; mu_d[0] += p_d[3 * i];
+            p_d[3 * i + 1] = r10 * x + r11 * y + r12 * z + t1; mu_d[1] += p_d[3 * i + 1];
+            p_d[3 * i + 2] = r20 * x + r21 * y + r22 * z + t2; mu_d[2] += p_d[3 * i + 2];
+            // the reference adds the double dis to the float sum and rounds back (jly_icp3d.hpp:268-276); dis holds a float value, and
+            // rounding the 53-bit sum of two floats to 24 bits is the float sum itself (53 >= 2*24+2), so a float add gives the same bits
+            err_new = err_new + dis;
         }
         if (err > 0 && err - err_new < err_diff * num) break;
         err = err_new;
         // the running means are divided by n (not num) and never reset (jly_icp3d.hpp:260-262,278-279)
         for (int k = 0; k < 3; k++) { mu_m[k] = mu_m[k] / (double)(float)n; mu_d[k] = mu_d[k] / (double)(float)n; }
+        // the nine sums of the cross-covariance, each in index order (one pass, nine independent accumulators)
         double H[9];
-        for (int a = 0; a < 3; a++) for (int b = 0; b < 3; b++) {
-            double s = 0;
-            for (int i = 0; i < num; i++) s += (p_d[3 * i + a] - mu_d[a]) * (p_m[3 * i + b] - mu_m[b]);
-            H[3 * a + b] = s;
+        {
+            double h0 = 0, h1 = 0, h2 = 0, h3 = 0, h4 = 0, h5 = 0, h6 = 0, h7 = 0, h8 = 0;
+            const double m0 = mu_m[0], m1 = mu_m[1], m2 = mu_m[2], d0 = mu_d[0], d1 = mu_d[1], d2 = mu_d[2];
+            for (int i = 0; i < num; i++) {
+                const double a0 = p_d[3 * i] - d0, a1 = p_d[3 * i + 1] - d1, a2 = p_d[3 * i + 2] - d2;
+                const double b0 = p_m[3 * i] - m0, b1 = p_m[3 * i + 1] - m1, b2 = p_m[3 * i + 2] - m2;
+                h0 += a0 * b0; h1 += a0 * b1; h2 += a0 * b2; h3 += a1 * b0; h4 += a1 * b1; h5 += a1 * b2; h6 += a2 * b0; h7 += a2 * b1; h8 += a2 * b2;
+            }
+            H[0] = h0; H[1] = h1; H[2] = h2; H[3] = h3; H[4] = h4; H[5] = h5; H[6] = h6; H[7] = h7; H[8] = h8;
         }
         double Rn[9], Rc[9], tc[3], t_[3];
         kabsch_rotation(H, Rn);
@@ -488,7 +506,11 @@ float GoICP::icp_run(Matrix& R, Matrix& t) {
         std::memcpy(Rd, Rc, sizeof Rc); std::memcpy(td, tc, sizeof tc);
     }
     icp_id_data_.resize(n); icp_id_model_.resize(n); icp_dis_.resize(n);
-    for (int i = 0; i < n; i++) { icp_id_data_[i] = pts[i].id_data; icp_id_model_[i] = pts[i].id_model; icp_dis_[i] = pts[i].dis; }
+    for (int i = 0; i < n; i++) {
+        const uint64_t v = ka[i]; const int id = (int)(uint32_t)v;
+        const uint32_t kbits = (uint32_t)(v >> 32); float dis; std::memcpy(&dis, &kbits, 4);
+        icp_id_data_[i] = id; icp_id_model_[i] = ids[id]; icp_dis_[i] = dis;
+    }
     for (int i = 0; i < 3; i++) { for (int j = 0; j < 3; j++) R.val[i][j] = Rd[3 * i + j]; t.val[i][0] = td[i]; }
     return err_new;
 }
