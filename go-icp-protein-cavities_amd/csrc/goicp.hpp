@@ -154,7 +154,7 @@ public:
 
 private:
     goicp_engine* eng_ = nullptr;
-    double icp_ms_ = 0, t_start_ms_ = 0;
+    double icp_ms_ = 0, icp_nn_ms_ = 0, t_start_ms_ = 0;
     std::vector<float> normData_, minDis_;
     std::vector<int32_t> icp_id_data_, icp_id_model_, opt_id_data_, opt_id_model_;
     std::vector<double> icp_dis_;

@@ -19,6 +19,7 @@
 #include "kabsch.hpp"
 
 namespace goicp {
+static double now_ms() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 
 properties string_to_prop(const std::string& t) {
     if (t == "OG") return OG; if (t == "N") return N; if (t == "O") return O; if (t == "NZ") return NZ;
@@ -427,7 +428,9 @@ float GoICP::icp_run(Matrix& R, Matrix& t) {
         stats.icp_iters++;
         const float r00 = (float)Rd[0], r01 = (float)Rd[1], r02 = (float)Rd[2], r10 = (float)Rd[3], r11 = (float)Rd[4], r12 = (float)Rd[5];
         const float r20 = (float)Rd[6], r21 = (float)Rd[7], r22 = (float)Rd[8], t0 = (float)td[0], t1 = (float)td[1], t2 = (float)td[2];
+        const double t_nn0 = now_ms();
         status = goicp_engine_icp_nn_ties(eng_, Rd, td, ids.data(), dsq.data(), tied.data());
+        icp_nn_ms_ += now_ms() - t_nn0;
         if (status != GOICP_OK) return std::numeric_limits<float>::quiet_NaN();
         for (int i = 0; i < n; i++) if (tied[i] > 1) {
             // several model points at exactly this distance: the reference's kd-tree keeps the first one it visits
@@ -611,7 +614,6 @@ void expand_plan(const ROTNODE& par, PopPlan& pl) {
 }
 }  // namespace
 
-static double now_ms() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 
 // reference jly_goicp.cpp:582-876
 float GoICP::OuterBnB() {
@@ -774,7 +776,7 @@ float GoICP::OuterBnB() {
 }
 
 float GoICP::Register() {
-    trace.clear(); stats = RegisterStats(); job_log.clear(); result_log.clear(); icp_ms_ = 0;
+    trace.clear(); stats = RegisterStats(); job_log.clear(); result_log.clear(); icp_ms_ = 0; icp_nn_ms_ = 0;
     const bool timing = getenv("GOICP_TIMING") != nullptr;
     const double t0 = now_ms();
     t_start_ms_ = t0; budget_hit = false;
@@ -793,9 +795,9 @@ float GoICP::Register() {
     if (timing) {
         uint64_t rounds = 0, launched = 0;
         goicp_engine_search_stats(eng_, &rounds, &launched);
-        fprintf(stderr, "[goicp timing] Initialize+engine %.1f ms, OuterBnB %.1f ms (ICP host+device %.1f ms); search rounds %llu, cube evals launched %llu, consumed %llu; "
+        fprintf(stderr, "[goicp timing] Initialize+engine %.1f ms, OuterBnB %.1f ms (ICP host+device %.1f ms, of which 1-NN launch+wait %.1f ms); search rounds %llu, cube evals launched %llu, consumed %llu; "
                         "launches %llu, jobs launched %llu consumed %llu, queue pops launched %llu consumed %llu, rot pops %llu\n",
-                t1 - t0, t2 - t1, icp_ms_, (unsigned long long)rounds, (unsigned long long)launched, (unsigned long long)stats.cube_evals,
+                t1 - t0, t2 - t1, icp_ms_, icp_nn_ms_, (unsigned long long)rounds, (unsigned long long)launched, (unsigned long long)stats.cube_evals,
                 (unsigned long long)stats.inner_launches, (unsigned long long)stats.inner_jobs_launched, (unsigned long long)stats.inner_calls,
                 (unsigned long long)stats.pops_launched, (unsigned long long)stats.trans_pops, (unsigned long long)stats.rot_pops);
     }

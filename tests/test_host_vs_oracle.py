@@ -102,3 +102,14 @@ def test_parallel_partition_formulation_equals_the_sequential_loop(tmp_path):
     subprocess.check_call(["gcc", "-O2", "-o", exe, os.path.join(os.path.dirname(__file__), "csrc", "partition_check.c")])
     out = subprocess.run([exe, "300000"], capture_output=True, text=True, timeout=120)
     assert out.returncode == 0 and out.stdout.strip() == "bad=0", out.stdout
+
+
+def test_wave_wide_queue_pop_equals_the_sequential_heap(tmp_path):
+    """heap_pop_wave (csrc/engine_dev.hpp) resolves a pop's path from ballots over sibling comparisons (six levels per round trip to the
+    queue) and lands the displaced element with one more ballot; tests/csrc/heap_pop_model.c restates it lane by lane and checks the
+    queue array against the sequential pop_heap order (reference jly_goicp.h:75-87 through std::priority_queue)."""
+    import subprocess
+    exe = str(tmp_path / "heap_pop_model")
+    subprocess.check_call(["gcc", "-O2", "-o", exe, os.path.join(os.path.dirname(__file__), "csrc", "heap_pop_model.c")])
+    out = subprocess.run([exe, "200000"], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0 and out.stdout.strip() == "bad=0", out.stdout
