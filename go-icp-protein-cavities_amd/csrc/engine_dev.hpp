@@ -1614,7 +1614,9 @@ struct HeapStoreT {
     }
 };
 typedef HeapStoreT<HeapNode> HeapStore;
-__device__ __forceinline__ bool key_lower(float plb, float pw, float qlb, float qw) { return plb != qlb ? plb > qlb : pw < qw; }
+// (the reference's `lb != lb' ? lb > lb' : w < w'` as mask arithmetic -- the same truth table, NaNs included -- so that a wave-wide compare is three
+// v_cmp and two scalar mask operations instead of a chain of selects)
+__device__ __forceinline__ bool key_lower(float plb, float pw, float qlb, float qw) { return (plb > qlb) | ((plb == qlb) & (pw < qw)); }
 struct HeapKey { float lb, w; };
 template <class N>
 __device__ __forceinline__ HeapKey heap_key(const HeapStoreT<N>& a, int i) {
