@@ -226,6 +226,11 @@ def main():
     cav = None
     if not args.no_register and args.cavity_rows > 0:
         cav = cavity_batch(goicp_amd, args, rank, world, local, use_dist, dist, dev, torch)
+        # the batch's pooled streams go back to the runtime here: while the 16 CU-masked search streams of its engines stay alive (idle, in the
+        # engine pool), every later launch of the process runs slower -- the registration leg below 60-72 ms instead of 43 ms, its search
+        # kernels 20-30 ms instead of 17.8 (tools: BENCH_KEEP_POOL=1 python bench.py --no-cpu --no-stress --overlap-pairs 1)
+        if not os.environ.get("BENCH_KEEP_POOL"):
+            goicp_amd.lib().goicp_engine_release_cached_memory()
 
     # ---- end-to-end registration of the same pair ------------------------------------------------------
     reg = None

@@ -130,8 +130,11 @@ int goicp_engine_num_slots(const goicp_engine* h);
 /* InnerBnB jobs (one workgroup each) that are resident on the device at once for this engine's geometry: a batch of at most
  * this many jobs runs as one wave of workgroups. The host's speculative batching sizes its launches with it. */
 int goicp_engine_resident_jobs(const goicp_engine* h);
-/* Device memory of destroyed engines is parked per process and reused by the next engine (hipMalloc/hipFree synchronise
- * the device); this returns the parked blocks to the driver. GOICP_CACHE_GB (default 16, 0 = off) bounds what is parked. */
+/* Device memory, streams, events and pinned buffers of destroyed engines are parked per process and reused by the next engine
+ * (hipMalloc/hipFree/hipStreamCreate synchronise the device); this returns the parked blocks and streams to the runtime.
+ * GOICP_CACHE_GB (default 16, 0 = off) bounds what is parked. Call it when a batch of cavity-sized registrations is over and the
+ * process goes on to other GPU work: the batch's CU-masked search streams slow every later launch down for as long as they exist
+ * (measured: a configs[2]-sized Register() 60-72 ms instead of 43 ms). */
 void goicp_engine_release_cached_memory(void);
 
 /* (cube) -> (ub, lb) for n cubes given as x,y,z,w quadruples, rotation slot `slot`, rot_level as in the job */

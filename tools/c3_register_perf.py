@@ -5,13 +5,16 @@ import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import numpy as np
+if os.environ.get("C3_WITH_TORCH"):          # the same inside a process that has PyTorch's HIP runtime up (as bench.py does)
+    import torch
+    torch.zeros(1, device="cuda")
 import goicp_amd
 from goicp_amd.synth import synth_pair
 
 reps = int(sys.argv[1]) if len(sys.argv) > 1 else 7
 P = synth_pair(5000, seed=20260101, theta_range=(2.2, 3.1))
 cfg = goicp_amd.cfg_vector(MSEThresh=0.001, trimFraction=0.1, regularization=0.0, regularizationFPFH=0.0, cfpfh=0, ponderation=0, norm=2, distTransSize=300)
-g = goicp_amd.GoICP(cfg, dt_mode=1); g.set_clouds(P["t"], P["s"]); g.build_dt()
+g = goicp_amd.GoICP(cfg, dt_mode=int(os.environ.get("C3_DT_MODE", "1"))); g.set_clouds(P["t"], P["s"]); g.build_dt()
 rows = []
 for r in range(reps + 1):
     g.clear()
