@@ -136,6 +136,50 @@ __global__ __launch_bounds__(256) void k_icp_nn(DevTables T, const float* __rest
     if (lane == 0) { id_out[i] = bi; d_out[i] = best; if (tie_out) tie_out[i] = cnt; }
 }
 
+// The same search with the model sorted along x (ICP3D::Run above cavity size: thousands of model points, hundreds of iterations).
+// ANY model point bounds the answer from above, and the point matched in the previous iteration bounds it tightly: with
+// dub = |q - model[prev]|^2, a point whose (q.x - x)^2 alone exceeds dub cannot be the nearest (float rounding is monotone, so the full
+// three-term sum is not smaller than its first term), and the survivors are a contiguous run of the x-sorted model, found through a table
+// of NN_BUCKETS bucket starts (one bucket of slack either side covers the rounding of the run's ends). Distances come from the same
+// expression on the same floats as k_icp_nn, the minimum, the lowest original index among exact ties and the tie count are those of the
+// full scan: every point at the minimal distance lies inside the run. An inlier scans a few per cent of the model, an outlier most of it.
+#define NN_BUCKETS 4096
+__global__ __launch_bounds__(256) void k_icp_nn_slab(DevTables T, const float* __restrict__ mxyz, const float4* __restrict__ mxs, const int* __restrict__ mxb,
+                                                      float x0, float inv, RtArg rt, int* __restrict__ prev,
+                                                      int* __restrict__ id_out, float* __restrict__ d_out, int* __restrict__ tie_out) {
+    const float* Rt = rt.v;
+    const int lane = threadIdx.x & 63;
+    const int i = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (i >= T.Nd) return;                         // whole waves leave together
+    const float d0 = T.dxyz[3 * i], d1 = T.dxyz[3 * i + 1], d2 = T.dxyz[3 * i + 2];
+    const float q0 = Rt[0] * d0 + Rt[1] * d1 + Rt[2] * d2 + Rt[9];
+    const float q1 = Rt[3] * d0 + Rt[4] * d1 + Rt[5] * d2 + Rt[10];
+    const float q2 = Rt[6] * d0 + Rt[7] * d1 + Rt[8] * d2 + Rt[11];
+    const int p = prev[i];
+    const float f0 = q0 - mxyz[3 * p], f1 = q1 - mxyz[3 * p + 1], f2 = q2 - mxyz[3 * p + 2];
+    const float dub = f0 * f0 + f1 * f1 + f2 * f2;
+    const float rr = sqrtf(dub) * 1.000002f;       // |q.x - x| of a survivor, with room for the roundings of the difference, the square and the root
+    const float bl = floorf((q0 - rr - x0) * inv), bh = floorf((q0 + rr - x0) * inv);
+    const int blo = (int)fminf(fmaxf(bl - 1.f, 0.f), (float)(NN_BUCKETS - 1)), bhi = (int)fminf(fmaxf(bh + 1.f, 0.f), (float)(NN_BUCKETS - 1));
+    const int s0 = mxb[blo], s1 = mxb[bhi + 1];
+    float best = INFINITY; int bi = 0x7fffffff, cnt = 0;
+    for (int s = s0 + lane; s < s1; s += 64) {
+        const float4 v = mxs[s];
+        const float e0 = q0 - v.x, e1 = q1 - v.y, e2 = q2 - v.z;
+        const float d = e0 * e0 + e1 * e1 + e2 * e2;
+        const int m = __float_as_int(v.w);
+        if (d < best) { best = d; bi = m; cnt = 1; }
+        else if (d == best) { cnt++; if (m < bi) bi = m; }
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        const float ob = __shfl_down(best, off, 64); const int oi = __shfl_down(bi, off, 64); const int oc = __shfl_down(cnt, off, 64);
+        if (ob < best) { best = ob; bi = oi; cnt = oc; }
+        else if (ob == best) { cnt += oc; if (oi < bi) bi = oi; }
+    }
+    if (lane == 0) { id_out[i] = bi; d_out[i] = best; if (tie_out) tie_out[i] = cnt; prev[i] = bi; }
+}
+
 // ---------------------------------------------------------------------------------------------
 // k_icp_loop: ICP3D<float>::Run (reference jly_icp3d.hpp:197-311) as ONE launch for cavity-sized, untrimmed clouds: the whole
 // iteration -- exhaustive 1-NN (the search of k_icp_nn), the running centroids (never reset, divided by n: the reference's quirks), the
@@ -669,6 +713,34 @@ extern "C" int goicp_engine_create(const goicp_engine_desc* d, goicp_engine** ou
     float* p_w; CR(dev_upload(h, d->weights, (size_t)d->Nd, &p_w)); T.weights = p_w;
     float* p_mrd; CR(dev_upload(h, d->maxRotDis, (size_t)GOICP_MAXROTLEVEL * d->Nd, &p_mrd)); T.maxRotDis = p_mrd;
     CR(dev_upload(h, d->model_xyz, (size_t)3 * d->Nm, &h->d_mxyz));
+    // 1-NN of ICP3D::Run above cavity size: the model sorted along x, bucket starts, and the last match of every data point (k_icp_nn_slab)
+    std::vector<float4> mxs; std::vector<int> mxb;
+    h->nn_slab = 0; h->d_mxs = nullptr; h->d_mxb = nullptr; h->d_prev = nullptr; h->mx_x0 = 0.f; h->mx_inv = 0.f;
+    if (d->Nm >= 1024 && !env_is_zero("GOICP_NN_SLAB")) {
+        float xmin = d->model_xyz[0], xmax = d->model_xyz[0];
+        for (int m = 1; m < d->Nm; m++) { xmin = std::min(xmin, d->model_xyz[3 * (size_t)m]); xmax = std::max(xmax, d->model_xyz[3 * (size_t)m]); }
+        if (xmax > xmin && std::isfinite(xmin) && std::isfinite(xmax)) {
+            h->mx_x0 = xmin; h->mx_inv = (float)NN_BUCKETS / (xmax - xmin);
+            std::vector<int> ord((size_t)d->Nm);
+            for (int m = 0; m < d->Nm; m++) ord[(size_t)m] = m;
+            std::sort(ord.begin(), ord.end(), [&](int a, int b) { const float xa = d->model_xyz[3 * (size_t)a], xb = d->model_xyz[3 * (size_t)b]; return xa != xb ? xa < xb : a < b; });
+            mxs.resize((size_t)d->Nm); mxb.assign(NN_BUCKETS + 1, 0);
+            for (int s = 0; s < d->Nm; s++) {
+                const int m = ord[(size_t)s]; const float* q = d->model_xyz + 3 * (size_t)m;
+                float4 v; v.x = q[0]; v.y = q[1]; v.z = q[2]; memcpy(&v.w, &m, 4);
+                mxs[(size_t)s] = v;
+                // the kernel's own bucket expression (monotone in x, so the buckets are runs of the sorted model)
+                const int b = (int)std::min(std::max(floorf((q[0] - h->mx_x0) * h->mx_inv), 0.f), (float)(NN_BUCKETS - 1));
+                mxb[(size_t)b + 1]++;
+            }
+            for (int b = 0; b < NN_BUCKETS; b++) mxb[(size_t)b + 1] += mxb[(size_t)b];
+            CR(dev_upload(h, mxs.data(), mxs.size(), &h->d_mxs));
+            CR(dev_upload(h, mxb.data(), mxb.size(), &h->d_mxb));
+            CR(dev_upload<int>(h, nullptr, (size_t)d->Nd, &h->d_prev));
+            HIPCHK(h, hipMemsetAsync(h->d_prev, 0, (size_t)d->Nd * sizeof(int), h->stream));
+            h->nn_slab = 1;
+        }
+    }
 
     // colour classes: the 8 known properties first, then whatever else appears (<= 16 classes in all)
     std::map<int, int> cls;
@@ -1052,14 +1124,16 @@ extern "C" int goicp_engine_icp_nn_ties(goicp_engine* h, const double* R9, const
         // small clouds (every ICP iteration of a cavity pair comes through here): the kernel writes its result arrays
         // straight into pinned host memory, so an iteration is one launch and one stream synchronisation
         int* pid = (int*)h->pinned; float* pd = (float*)h->pinned + Nd; int* pt = (int*)h->pinned + 2 * Nd;
-        hipLaunchKernelGGL(k_icp_nn, dim3((h->T.Nd + 3) / 4), dim3(256), 0, h->stream_hi, h->T, h->d_mxyz, rt, pid, pd, n_tied ? pt : nullptr);
+        if (h->nn_slab) hipLaunchKernelGGL(k_icp_nn_slab, dim3((h->T.Nd + 3) / 4), dim3(256), 0, h->stream_hi, h->T, h->d_mxyz, h->d_mxs, h->d_mxb, h->mx_x0, h->mx_inv, rt, h->d_prev, pid, pd, n_tied ? pt : nullptr);
+        else hipLaunchKernelGGL(k_icp_nn, dim3((h->T.Nd + 3) / 4), dim3(256), 0, h->stream_hi, h->T, h->d_mxyz, rt, pid, pd, n_tied ? pt : nullptr);
         HIPCHK(h, hipGetLastError());
         HIPCHK(h, wait_stream(h, h->stream_hi));
         memcpy(id_model, pid, Nd * sizeof(int)); memcpy(dist_sq, pd, Nd * sizeof(float));
         if (n_tied) memcpy(n_tied, pt, Nd * sizeof(int));
         return GOICP_OK;
     }
-    hipLaunchKernelGGL(k_icp_nn, dim3((h->T.Nd + 3) / 4), dim3(256), 0, h->stream_hi, h->T, h->d_mxyz, rt, h->d_int, h->d_dist, n_tied ? h->d_tie : nullptr);
+    if (h->nn_slab) hipLaunchKernelGGL(k_icp_nn_slab, dim3((h->T.Nd + 3) / 4), dim3(256), 0, h->stream_hi, h->T, h->d_mxyz, h->d_mxs, h->d_mxb, h->mx_x0, h->mx_inv, rt, h->d_prev, h->d_int, h->d_dist, n_tied ? h->d_tie : nullptr);
+    else hipLaunchKernelGGL(k_icp_nn, dim3((h->T.Nd + 3) / 4), dim3(256), 0, h->stream_hi, h->T, h->d_mxyz, rt, h->d_int, h->d_dist, n_tied ? h->d_tie : nullptr);
     HIPCHK(h, hipGetLastError());
     HIPCHK(h, hipMemcpyAsync(id_model, h->d_int, (size_t)h->T.Nd * sizeof(int), hipMemcpyDeviceToHost, h->stream_hi));
     HIPCHK(h, hipMemcpyAsync(dist_sq, h->d_dist, (size_t)h->T.Nd * sizeof(float), hipMemcpyDeviceToHost, h->stream_hi));

@@ -17,6 +17,7 @@ struct goicp_engine {
     std::vector<void*> allocs;
     // device buffers
     float* d_mxyz; float4* d_rot; float* d_R; int nslots;
+    float4* d_mxs; int* d_mxb; int* d_prev; float mx_x0, mx_inv; int nn_slab;   // model sorted along x + bucket starts + last match per data point (k_icp_nn_slab)
     goicp_bnb_job* d_jobs; goicp_bnb_result* d_results; int job_cap;
     HeapNode* d_heaps; int heap_cap; size_t heap_jobs; HeapNode* d_heap_big; int heap_big_cap;
     float* d_fpscratch; size_t fp_blocks;
