@@ -121,11 +121,20 @@ __global__ __launch_bounds__(256) void k_icp_nn(DevTables T, const float* __rest
     const float q1 = Rt[3] * d0 + Rt[4] * d1 + Rt[5] * d2 + Rt[10];
     const float q2 = Rt[6] * d0 + Rt[7] * d1 + Rt[8] * d2 + Rt[11];
     float best = INFINITY; int bi = 0x7fffffff, cnt = 0;
-    for (int m = lane; m < T.Nm; m += 64) {
-        const float e0 = q0 - mxyz[3 * m], e1 = q1 - mxyz[3 * m + 1], e2 = q2 - mxyz[3 * m + 2];
-        const float d = e0 * e0 + e1 * e1 + e2 * e2;
-        if (d < best) { best = d; bi = m; cnt = 1; }
-        else if (d == best) cnt++;
+    // four model points per lane and trip, their loads issued together: a wave walks its points alone on its SIMD most of the time, so a
+    // trip costs one memory latency however little it computes (one point per trip: 78 latencies per query at 5 000 model points)
+    for (int m0 = lane; m0 < T.Nm; m0 += 256) {
+        float x[4], y[4], z[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) { const int m = min(m0 + 64 * k, T.Nm - 1); x[k] = mxyz[3 * m]; y[k] = mxyz[3 * m + 1]; z[k] = mxyz[3 * m + 2]; }
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const int m = m0 + 64 * k;
+            const float e0 = q0 - x[k], e1 = q1 - y[k], e2 = q2 - z[k];
+            const float d = e0 * e0 + e1 * e1 + e2 * e2;
+            const bool ok = m < T.Nm, lt = ok & (d < best), eq = ok & (d == best);
+            cnt = lt ? 1 : cnt + (eq ? 1 : 0); bi = lt ? m : bi; best = lt ? d : best;
+        }
     }
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) {
@@ -163,13 +172,18 @@ __global__ __launch_bounds__(256) void k_icp_nn_slab(DevTables T, const float* _
     const int blo = (int)fminf(fmaxf(bl - 1.f, 0.f), (float)(NN_BUCKETS - 1)), bhi = (int)fminf(fmaxf(bh + 1.f, 0.f), (float)(NN_BUCKETS - 1));
     const int s0 = mxb[blo], s1 = mxb[bhi + 1];
     float best = INFINITY; int bi = 0x7fffffff, cnt = 0;
-    for (int s = s0 + lane; s < s1; s += 64) {
-        const float4 v = mxs[s];
-        const float e0 = q0 - v.x, e1 = q1 - v.y, e2 = q2 - v.z;
-        const float d = e0 * e0 + e1 * e1 + e2 * e2;
-        const int m = __float_as_int(v.w);
-        if (d < best) { best = d; bi = m; cnt = 1; }
-        else if (d == best) { cnt++; if (m < bi) bi = m; }
+    for (int t0 = s0 + lane; t0 < s1; t0 += 256) {            // four points per lane and trip, loads issued together (see k_icp_nn)
+        float4 v[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) v[k] = mxs[min(t0 + 64 * k, s1 - 1)];
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const float e0 = q0 - v[k].x, e1 = q1 - v[k].y, e2 = q2 - v[k].z;
+            const float d = e0 * e0 + e1 * e1 + e2 * e2;
+            const int m = __float_as_int(v[k].w);
+            const bool ok = t0 + 64 * k < s1, lt = ok & (d < best), eq = ok & (d == best);
+            cnt = lt ? 1 : cnt + (eq ? 1 : 0); bi = lt ? m : (eq ? min(bi, m) : bi); best = lt ? d : best;
+        }
     }
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) {

@@ -134,6 +134,47 @@ def test_point_eval_and_icp_nn_against_oracle():
     e.close()
 
 
+def test_icp_nn_on_the_sorted_model_equals_the_exhaustive_search(monkeypatch):
+    """Models of >= 1024 points are searched through their x-sorted copy, bounded by the point matched in the previous call (k_icp_nn_slab):
+    squared distance, lowest tied index and tie count must be those of the exhaustive float search (the expression of the reference's
+    kd-tree metric, jly_icp3d.hpp:54-60) -- with duplicated model points (exact ties), outliers far outside the model's extent, a sequence
+    of poses (the bound carried from call to call) and the exhaustive kernel of the same library (GOICP_NN_SLAB=0) as a second witness."""
+    rng = np.random.default_rng(99)
+    Nm, Nd = 3000, 1500
+    m = rng.uniform(-0.6, 0.6, (Nm, 3)).astype(np.float32)
+    m[Nm - 300:] = m[:300]                                    # 300 exact duplicates: ties between index k and Nm-300+k
+    m[100:140, 0] = m[100, 0]                                 # equal x coordinates (one bucket boundary, many points)
+    dpts = rng.uniform(-0.6, 0.6, (Nd, 3)).astype(np.float32)
+    dpts[:150] *= np.float32(4.0)                             # outliers: their run covers the whole model
+    dpts[200:260] = m[:60]                                    # exact hits at the identity pose
+    S = 20; dist = np.zeros(S ** 3, np.float32)
+
+    def make():
+        return goicp_amd.Engine(S=S, geom4=(-1.0, -1.0, -1.0, S / 2.0), dist=dist, data_xyz=dpts, weights=np.ones(Nd, np.float32),
+                                maxrotdis=np.zeros(20 * Nd, np.float32), model_xyz=m, inlier_num=Nd)
+    e = make()
+    monkeypatch.setenv("GOICP_NN_SLAB", "0"); e0 = make(); monkeypatch.delenv("GOICP_NN_SLAB")
+    poses = [(np.eye(3), np.zeros(3))]
+    for _ in range(6):
+        aa = rng.uniform(-1, 1, 3); th = np.linalg.norm(aa); k = aa / th
+        K = np.array([[0, -k[2], k[1]], [k[2], 0, -k[0]], [-k[1], k[0], 0]])
+        poses.append((np.eye(3) + np.sin(th) * K + (1 - np.cos(th)) * K @ K, rng.uniform(-0.2, 0.2, 3)))
+    poses.append(poses[-1]); poses.append(poses[0])
+    for R, t in poses:
+        ids, d, nt = e.icp_nn(R, t, ties=True)
+        ids0, d0, nt0 = e0.icp_nn(R, t, ties=True)
+        Rf = R.astype(np.float32); tf = t.astype(np.float32)
+        qf = np.stack([((Rf[a, 0] * dpts[:, 0] + Rf[a, 1] * dpts[:, 1]) + Rf[a, 2] * dpts[:, 2]) + tf[a] for a in range(3)], 1).astype(np.float32)
+        dd = qf[:, None, :] - m[None, :, :]
+        d2 = ((dd[..., 0] * dd[..., 0] + dd[..., 1] * dd[..., 1]) + dd[..., 2] * dd[..., 2]).astype(np.float32)
+        best = d2.min(1)
+        assert np.array_equal(d, best) and np.array_equal(d0, best)
+        assert np.array_equal(ids, (d2 == best[:, None]).argmax(1)) and np.array_equal(ids0, ids)        # lowest index at the minimum
+        assert np.array_equal(nt, (d2 == best[:, None]).sum(1)) and np.array_equal(nt0, nt)
+    assert (nt > 1).any()
+    e.close(); e0.close()
+
+
 @pytest.mark.parametrize("name", ["pair1_default", "pair1_trim", "pair1_fpfh"])
 def test_icp_against_reference_fixtures(name):
     """GoICP::ICP through the C ABI (goicp_icp) on the compiled reference's in/out records (tests/golden/icp_*.npz): error,
