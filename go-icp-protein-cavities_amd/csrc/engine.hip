@@ -731,9 +731,9 @@ extern "C" int goicp_engine_create(const goicp_engine_desc* d, goicp_engine** ou
     std::vector<float4> mxs; std::vector<int> mxb;
     h->nn_slab = 0; h->d_mxs = nullptr; h->d_mxb = nullptr; h->d_prev = nullptr; h->mx_x0 = 0.f; h->mx_inv = 0.f;
     if (d->Nm >= 1024 && !env_is_zero("GOICP_NN_SLAB")) {
-        float xmin = d->model_xyz[0], xmax = d->model_xyz[0];
-        for (int m = 1; m < d->Nm; m++) { xmin = std::min(xmin, d->model_xyz[3 * (size_t)m]); xmax = std::max(xmax, d->model_xyz[3 * (size_t)m]); }
-        if (xmax > xmin && std::isfinite(xmin) && std::isfinite(xmax)) {
+        float xmin = d->model_xyz[0], xmax = d->model_xyz[0]; bool finite = true;
+        for (int m = 0; m < d->Nm; m++) { const float x = d->model_xyz[3 * (size_t)m]; finite = finite && std::isfinite(x); xmin = std::min(xmin, x); xmax = std::max(xmax, x); }
+        if (finite && xmax > xmin) {                         // (a model without extent along x, or with a non-finite x, keeps the exhaustive kernel)
             h->mx_x0 = xmin; h->mx_inv = (float)NN_BUCKETS / (xmax - xmin);
             std::vector<int> ord((size_t)d->Nm);
             for (int m = 0; m < d->Nm; m++) ord[(size_t)m] = m;
