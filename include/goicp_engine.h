@@ -153,7 +153,9 @@ int goicp_engine_inner_bnb_batch(goicp_engine* h, const goicp_bnb_job* jobs, int
 
 /* q_i = (float)(R*p_i + t) (double R,t); dist[i] = DT(q_i) (unweighted); compat[i] = 1/0 (may be NULL) */
 int goicp_engine_point_eval(goicp_engine* h, const double* R9, const double* t3, float* dist, int32_t* compat);
-/* q_i = R*p_i + t in float (R,t rounded from double); nearest model point id and squared distance */
+/* q_i = R*p_i + t in float (R,t rounded from double); nearest model point id and squared distance. Models of >= 1024 points are searched
+ * through a copy sorted along x, bounded by each point's match of the previous call on this engine (same results as the exhaustive
+ * search, GOICP_NN_SLAB=0 forces that one) */
 int goicp_engine_icp_nn(goicp_engine* h, const double* R9, const double* t3, int32_t* id_model, float* dist_sq);
 /* the same search (kdtree->knnSearch(query, 1, ...), reference jly_icp3d.hpp:245) plus n_tied[i] = number of model points at
  * exactly the minimal float distance of query i (id_model[i] is then the lowest of them). The reference's kd-tree keeps the
