@@ -265,10 +265,13 @@ def main():
                                   error=float(out2["error"]), dR_vs_planted=float(np.abs(out2["R"] - P["Rtrue"]).max()),
                                   note="dt_mode=1: exact Euclidean transform built on the GPU (not bit-identical to the reference's propagated grid; opt-in)"))
         if args.overlap_pairs > 1:
-            reg.update(overlapped_registrations(goicp_amd, synth_pair, cfg, nd, args.overlap_pairs, local, world, rank, use_dist, dist, dev, torch))
+            from goicp_amd import driver
+            # host-built grids: the builds are CPU work that fills the CPU budget whatever the thread count, one pair per budgeted CPU
+            reg.update(overlapped_registrations(goicp_amd, synth_pair, cfg, nd, max(2, min(args.overlap_pairs, driver.host_cpu_budget() // max(1, world))), local, world, rank, use_dist, dist, dev, torch))
+            nov = driver.worker_threads(args.overlap_pairs, world)          # spinning waits: two CPUs of the budget stay free (14 of a 16-CPU quota)
             # the same with the device-built grid: 4 x as many pairs, the same number of registrations in flight
-            reg["device_dt"].update(overlapped_registrations(goicp_amd, synth_pair, cfg, nd, 4 * args.overlap_pairs, local, world, rank, use_dist, dist, dev, torch,
-                                                             dt_mode=1, threads=args.overlap_pairs, tag="in_flight"))
+            reg["device_dt"].update(overlapped_registrations(goicp_amd, synth_pair, cfg, nd, 4 * nov, local, world, rank, use_dist, dist, dev, torch,
+                                                             dt_mode=1, threads=nov, tag="in_flight"))
 
     # ---- CPU baseline: the unmodified reference (oracle/_ref) replaying the same InnerBnB calls, bounded -------
     cpu = None
@@ -415,8 +418,8 @@ def cavity_batch(goicp_amd, args, rank, world, local, use_dist, dist, dev, torch
     # kernels, pooled streams / pinned buffers / device blocks of 16 engines), as the metric leg has its warm-up launches
     warm = min(32, max(1, args.cavity_rows // world))
     # host threads (= registrations in flight) per rank: the waits spin, so never more threads than this rank's share of the host cores
-    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
-    threads = max(1, min(args.cavity_threads, cores // max(1, world)))
+    cores = driver.host_cpu_budget()                      # affinity set or cgroup CPU quota, whichever is smaller (16 on a one-GPU box)
+    threads = driver.worker_threads(args.cavity_threads, world, cores)
     driver.run_batch(base, tsv, cfgp, os.path.join(base, "warm_r%d" % rank), driver.gpu_register_fn(base, device_id=local), rank=rank, world=world,
                      threads=threads, limit=min(args.cavity_rows, warm * world), schedule="rr", rmsd=False)      # (disjoint rows per rank: the pipeline writes per-row files)
     if use_dist:

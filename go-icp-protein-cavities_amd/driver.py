@@ -201,6 +201,34 @@ def list_jobs(base_dir, tsv, limit=None):
     return jobs, len(pairs)
 
 
+def host_cpu_budget():
+    """CPUs this process may keep busy: the smaller of its affinity set and its cgroup's CFS quota (cpu.max of cgroup v2, cfs_quota_us /
+    cfs_period_us of v1). A GPU box hands a job 16 CPUs' worth of QUOTA on 256 visible CPUs; worker threads that spin on the device
+    (the default wait) burn the quota, and a cgroup over its quota has ALL its threads stopped until the next period: 16 spinning threads
+    plus the runtime's helpers ran the configs[3] batch at 370 pairs/s with 8-10 throttling events, 14 threads at 540 with one
+    (tools/throttle_probe.sh)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if q != "max":
+            n = min(n, max(1, int(float(q) / float(per))))
+    except (OSError, ValueError):
+        try:
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read()); per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0 and per > 0:
+                n = min(n, max(1, q // per))
+        except (OSError, ValueError):
+            pass
+    return n
+
+
+def worker_threads(wanted, world=1, budget=None):
+    """Registrations to keep in flight on this rank: `wanted`, but never more spinning threads than this rank's share of the CPU budget
+    minus two (the main thread and the HIP runtime's helpers need the rest)."""
+    b = host_cpu_budget() if budget is None else budget
+    return max(1, min(int(wanted), b // max(1, int(world)) - 2))
+
+
 def run_batch(base_dir, tsv, config, out_dir, register_fn, rank=0, world=1, limit=None, threads=1, schedule=None, dist=None, rmsd=True,
               counter_key="goicp_batch_next"):
     """register_fn(target_file, source_file, nd, config, output, k) -> result dict. Rows whose cavity files are missing are

@@ -232,3 +232,11 @@ def test_threaded_batch_returns_the_same_records_in_row_order(tmp_path):
     par, n2 = driver.run_batch(DATA, tsv, "unused", str(tmp_path), _fake_register, threads=4, rmsd=False)
     assert n1 == n2 == 383 and len(seq) == len(par) == 2
     assert all(np.array_equal(a, b, equal_nan=True) for a, b in zip(seq, par))
+
+
+def test_worker_threads_leave_two_cpus_of_the_budget_free():
+    """driver.worker_threads: spinning worker threads never fill this rank's share of the CPU budget (affinity set or cgroup quota)."""
+    from goicp_amd import driver
+    assert driver.host_cpu_budget() >= 1
+    assert driver.worker_threads(16, 1, 16) == 14 and driver.worker_threads(16, 8, 128) == 14
+    assert driver.worker_threads(4, 1, 16) == 4 and driver.worker_threads(16, 1, 2) == 1 and driver.worker_threads(16, 2, 16) == 6
