@@ -497,7 +497,11 @@ def cpu_baseline(g, P, cfg, args, reg):
                      "%d result mismatches > 1e-5)" % (ncalls, evals_counted, spent, mismatches),
            "host_cpus": os.cpu_count()}
     # all host cores: W worker processes (each its own copy of the reference and of the grid) over disjoint shares of the calls
-    W = args.cpu_workers if args.cpu_workers > 0 else min(os.cpu_count() or 1, 32)
+    # (as many as the CPU budget carries: a box shows 256 CPUs but its cgroup has a quota of 16 -- 32 workers would only share those)
+    from goicp_amd import driver
+    budget = driver.host_cpu_budget()
+    W = args.cpu_workers if args.cpu_workers > 0 else min(budget, 32)
+    out["cpu_budget"] = budget
     if W > 1:
         try:
             path = os.path.join(tempfile.gettempdir(), "goicp_cpu_jobs_%d.npz" % os.getpid())
