@@ -224,7 +224,10 @@ def host_cpu_budget():
 
 def worker_threads(wanted, world=1, budget=None):
     """Registrations to keep in flight on this rank: `wanted`, but never more spinning threads than this rank's share of the CPU budget
-    minus two (the main thread and the HIP runtime's helpers need the rest)."""
+    minus two (the main thread and the HIP runtime's helpers need the rest). Threads that sleep while they wait (GOICP_WAIT=block,
+    GOICP_SCHED=yield|block) do not burn the budget: `wanted` stands."""
+    if os.environ.get("GOICP_WAIT") == "block" or os.environ.get("GOICP_SCHED") in ("yield", "block"):
+        return max(1, int(wanted))
     b = host_cpu_budget() if budget is None else budget
     return max(1, min(int(wanted), b // max(1, int(world)) - 2))
 
