@@ -373,6 +373,11 @@ def _unpack24(r):
                 dt_seconds=float(r[16]), t_rescaled=r[17:20].copy(), cube_evals=int(r[20]), trans_pops=int(r[21]), rot_pops=int(r[22]), status=int(r[23]))
 
 
+def set_batch_speculation(depth):
+    """Speculation depth of run_pair_files for the whole process (include/goicp_c.h: goicp_set_batch_speculation); -1 = class default."""
+    load_library().goicp_set_batch_speculation(int(depth))
+
+
 def run_pair_files(base_dir, target_mol2, source_mol2, nd, config, output, pair, device_id=0, verbose=0):
     """The reference's main() on files (argv order of reference README.md:17)."""
     L = load_library()

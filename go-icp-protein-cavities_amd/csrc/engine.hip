@@ -19,6 +19,9 @@
 // that cell -- jly_goicp.cpp:974-1000,1068-1092 folded into one gather); nearest-occupied compact id
 // int32[S^3] + CSR of model points per occupied cell + c-FPFH rows (only when regularizationFPFH>0).
 #include "engine_host.hpp"
+#include <sys/prctl.h>
+#include <time.h>
+#include <chrono>
 
 #include "pool.hpp"
 #include "kabsch.hpp"
@@ -417,6 +420,8 @@ struct DevCache {
     std::vector<Queue> queues;                 // idle (stream, event, event) triples of destroyed engines
     struct Aux { int device, kind; hipStream_t stream; };
     std::vector<Aux> aux_streams;              // idle auxiliary streams (cache_stream_aux)
+    struct SharedHi { std::vector<hipStream_t> streams; size_t next = 0; };
+    std::map<int, SharedHi> shared_hi;         // per device: the high-priority streams all engines share (GOICP_HI_SHARE)
     static size_t size_class(size_t n) {
         if (n <= 256) return 256;
         if (n < ((size_t)1 << 20)) { size_t p2 = 256; while (p2 < n) p2 <<= 1; return p2; }
@@ -495,20 +500,36 @@ void cache_queue_return(int device, hipStream_t st, hipEvent_t e0, hipEvent_t e1
 // evaluation). kind 1: the bulk stream of cavity-sized engines' search launches (k_inner_bnb, hundreds to thousands of workgroups that hold a
 // CU's whole register file two at a time), confined to all but GOICP_CU_RESERVE (default 16) CUs -- beside other engines' launches the small
 // kernels otherwise wait for search workgroups to retire (configs[3] batch, 16 registrations in flight: 313 -> 390 pairs/s).
+static int hi_share_count() { static const int n = [] { const char* e = getenv("GOICP_HI_SHARE"); return e ? std::max(0, atoi(e)) : 0; }(); return n; }
+static hipError_t create_priority_stream(hipStream_t* st) {
+    int lo = 0, hi = 0;                                        // (numerically lower = higher priority)
+    if (hipDeviceGetStreamPriorityRange(&lo, &hi) != hipSuccess) { lo = 0; hi = 0; }
+    if (hipStreamCreateWithPriority(st, hipStreamNonBlocking, hi) == hipSuccess) return hipSuccess;
+    (void)hipGetLastError();
+    return hipStreamCreateWithFlags(st, hipStreamNonBlocking);
+}
 hipError_t cache_stream_aux(int device, int kind, hipStream_t* st) {
+    if (kind == 0 && hi_share_count() > 0) {
+        // GOICP_HI_SHARE=P: P high-priority streams per device for ALL engines (round robin) instead of one each. Every priority or CU-masked
+        // stream is a hardware queue of its own, and past ~36 queues per process the GPU time-slices them: the configs[3] batch falls from
+        // 557 pairs/s with 16 engines to 354 with 18. Engines wait on their own event, not on the stream.
+        std::lock_guard<std::mutex> lk(g_cache.mu);
+        auto& v = g_cache.shared_hi[device];
+        if ((int)v.streams.size() < hi_share_count()) {
+            hipStream_t s = nullptr; const hipError_t e = create_priority_stream(&s);
+            if (e != hipSuccess) return e;
+            v.streams.push_back(s); *st = s; return hipSuccess;
+        }
+        *st = v.streams[v.next++ % v.streams.size()];
+        return hipSuccess;
+    }
     {
         std::lock_guard<std::mutex> lk(g_cache.mu);
         for (size_t k = 0; k < g_cache.aux_streams.size(); k++) if (g_cache.aux_streams[k].device == device && g_cache.aux_streams[k].kind == kind) {
             *st = g_cache.aux_streams[k].stream; g_cache.aux_streams.erase(g_cache.aux_streams.begin() + k); return hipSuccess;
         }
     }
-    if (kind == 0) {
-        int lo = 0, hi = 0;                                    // (numerically lower = higher priority)
-        if (hipDeviceGetStreamPriorityRange(&lo, &hi) != hipSuccess) { lo = 0; hi = 0; }
-        if (hipStreamCreateWithPriority(st, hipStreamNonBlocking, hi) == hipSuccess) return hipSuccess;
-        (void)hipGetLastError();
-        return hipStreamCreateWithFlags(st, hipStreamNonBlocking);
-    }
+    if (kind == 0) return create_priority_stream(st);
     int reserve = 16, ncu = 0;
     { const char* r = getenv("GOICP_CU_RESERVE"); if (r) reserve = atoi(r); }
     if (reserve > 0 && hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && 2 * reserve <= ncu) {
@@ -521,17 +542,39 @@ hipError_t cache_stream_aux(int device, int kind, hipStream_t* st) {
 }
 void cache_stream_aux_return(int device, int kind, hipStream_t st) {
     if (!st) return;
+    if (kind == 0 && hi_share_count() > 0) return;           // shared: stays with the pool
     {
         std::lock_guard<std::mutex> lk(g_cache.mu);
         if (!g_cache.off && g_cache.aux_streams.size() < 128) { g_cache.aux_streams.push_back({device, kind, st}); return; }
     }
     (void)hipStreamDestroy(st);
 }
+// GOICP_WAIT=nap: a host thread that spins on the device burns a CPU of the process's budget for the whole kernel; most waits of a
+// cavity-sized registration are for launches of hundreds of microseconds. Poll the stream instead: spin for the first spin_us (short
+// kernels return inside it), then sleep nap_us between polls (timer slack lowered once per thread so that a nap is a nap).
+template <class Q>
+static hipError_t wait_nap_impl(Q query, int spin_us, int nap_us) {
+    static thread_local bool slack_set = false;
+    if (!slack_set) { (void)prctl(PR_SET_TIMERSLACK, 1000UL, 0, 0, 0); slack_set = true; }
+    const auto t0 = std::chrono::steady_clock::now();
+    for (;;) {
+        const hipError_t e = query();
+        if (e != hipErrorNotReady) return e;
+        const long us = (long)std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - t0).count();
+        if (us < spin_us) { __builtin_ia32_pause(); continue; }
+        struct timespec ts; ts.tv_sec = 0; ts.tv_nsec = (long)nap_us * 1000L;
+        (void)nanosleep(&ts, nullptr);
+    }
+}
+hipError_t wait_event_nap(hipEvent_t ev, int spin_us, int nap_us) { return wait_nap_impl([ev] { return hipEventQuery(ev); }, spin_us, nap_us); }
+hipError_t wait_stream_nap(hipStream_t st, int spin_us, int nap_us) { return wait_nap_impl([st] { return hipStreamQuery(st); }, spin_us, nap_us); }
 extern "C" void goicp_engine_release_cached_memory(void) {
     std::vector<void*> blocks;
     std::vector<DevCache::Queue> qs;
     std::vector<DevCache::Aux> aux;
-    { std::lock_guard<std::mutex> lk(g_cache.mu); for (auto& kv : g_cache.parked) blocks.push_back(kv.second); g_cache.parked.clear(); g_cache.parked_bytes = 0; qs.swap(g_cache.queues); aux.swap(g_cache.aux_streams); }
+    { std::lock_guard<std::mutex> lk(g_cache.mu); for (auto& kv : g_cache.parked) blocks.push_back(kv.second); g_cache.parked.clear(); g_cache.parked_bytes = 0; qs.swap(g_cache.queues); aux.swap(g_cache.aux_streams);
+      for (auto& kv : g_cache.shared_hi) for (hipStream_t s : kv.second.streams) aux.push_back({kv.first, 0, s});      // (no engine may be alive: see the header)
+      g_cache.shared_hi.clear(); }
     for (auto& q : aux) (void)hipStreamDestroy(q.stream);
     for (void* p : blocks) (void)hipFree(p);
     for (auto& q : qs) { (void)hipEventDestroy(q.ev0); (void)hipEventDestroy(q.ev1); (void)hipStreamDestroy(q.stream); if (q.pinned) (void)hipHostFree(q.pinned); }
@@ -562,7 +605,8 @@ extern "C" void goicp_engine_destroy(goicp_engine* h) {
     if (!h) return;
     (void)hipSetDevice(h->device);
     if (h->stream) (void)hipStreamSynchronize(h->stream);          // parked blocks must be idle
-    if (h->stream_hi) { (void)hipStreamSynchronize(h->stream_hi); cache_stream_aux_return(h->device, 0, h->stream_hi); }
+    if (h->stream_hi && !h->hi_shared) { (void)hipStreamSynchronize(h->stream_hi); cache_stream_aux_return(h->device, 0, h->stream_hi); }
+    if (h->ev_hi) { (void)hipEventSynchronize(h->ev_hi); (void)hipEventDestroy(h->ev_hi); }
     if (h->stream_bulk) { (void)hipStreamSynchronize(h->stream_bulk); cache_stream_aux_return(h->device, 1, h->stream_bulk); }
     if (h->ev_wait) (void)hipEventDestroy(h->ev_wait);
     for (void* p : h->allocs) cache_free(p);
@@ -655,7 +699,7 @@ extern "C" int goicp_engine_create(const goicp_engine_desc* d, goicp_engine** ou
 
     goicp_engine* h = new goicp_engine();
     memset(&h->T, 0, sizeof h->T);
-    h->device = d->device_id; h->stream = nullptr; h->ev0 = h->ev1 = nullptr; h->stream_hi = nullptr; h->stream_bulk = nullptr; h->ev_wait = nullptr; h->wait_block = 0; h->upload_defer = 1;
+    h->device = d->device_id; h->stream = nullptr; h->ev0 = h->ev1 = nullptr; h->stream_hi = nullptr; h->stream_bulk = nullptr; h->ev_wait = nullptr; h->ev_hi = nullptr; h->hi_shared = 0; h->wait_block = 0; h->upload_defer = 1;
     h->streamed = 0; h->stream_wgs = 0; h->stream_rot_wgs = 0; h->pinned = nullptr;
     h->d_heaps = nullptr; h->d_fpscratch = nullptr; h->heap_cap = 8192; h->heap_jobs = 0; h->fp_blocks = 0; h->d_heap_big = nullptr; h->heap_big_cap = 0;
     h->n_cubes = h->n_lookups = 0; h->kernel_ms = 0; h->max_pops = 200000000u;
@@ -676,7 +720,10 @@ extern "C" int goicp_engine_create(const goicp_engine_desc* d, goicp_engine** ou
     CRH(hipSetDevice(h->device));
     CRH(cache_queue(h->device, &h->stream, &h->ev0, &h->ev1, &h->pinned));
     CRH(cache_stream_aux(h->device, 0, &h->stream_hi));
-    { const char* e = getenv("GOICP_WAIT"); h->wait_block = (e && !strcmp(e, "block")) ? 1 : 0; }
+    h->hi_shared = hi_share_count() > 0 ? 1 : 0; h->ev_hi = nullptr;
+    if (h->hi_shared) CRH(hipEventCreateWithFlags(&h->ev_hi, hipEventDisableTiming));
+    { const char* e = getenv("GOICP_WAIT"); h->wait_block = (e && !strcmp(e, "block")) ? 1 : 0; h->wait_spin_us = 40; h->wait_nap_us = 40;
+      if (e && !strncmp(e, "nap", 3)) { h->wait_block = 2; int a = 0, b = 0; const int k = sscanf(e, "nap:%d:%d", &a, &b); if (k >= 1 && a >= 0) h->wait_spin_us = a; if (k >= 2 && b > 0) h->wait_nap_us = b; } }
     if (h->wait_block) CRH(hipEventCreateWithFlags(&h->ev_wait, hipEventBlockingSync | hipEventDisableTiming));
     DevTables& T = h->T;
     T.S = d->S; T.xMin = d->xMin; T.yMin = d->yMin; T.zMin = d->zMin; T.scale = d->scale;

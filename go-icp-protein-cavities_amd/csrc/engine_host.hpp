@@ -10,7 +10,9 @@ struct goicp_engine {
     hipStream_t stream_bulk;                  // search launches of cavity-sized engines (see cache_stream_aux); null: they use `stream`
     hipStream_t stream_hi;                    // high-priority stream for the small latency-critical kernels (ICP 1-NN, point evaluation): beside other
                                               // engines' bulk search launches they would otherwise queue behind thousands of search workgroups
-    hipEvent_t ev_wait; int wait_block;       // host waits: spin on the stream (default) or sleep on a blocking event (GOICP_WAIT=block; more host threads than cores)
+    hipEvent_t ev_wait; int wait_block;       // host waits: 0 spin on the stream (default), 1 sleep on a blocking event (GOICP_WAIT=block), 2 poll with naps (GOICP_WAIT=nap[:spin_us[:nap_us]])
+    int wait_spin_us, wait_nap_us;
+    hipEvent_t ev_hi; int hi_shared;           // stream_hi is one of a few shared by all engines (GOICP_HI_SHARE): waits go through this engine's own event
     void* pinned;                             // PINNED_BYTES of host memory (may be null), travels with the stream in the pool
     hipEvent_t ev0, ev1;
     DevTables T;
@@ -51,7 +53,15 @@ void cache_stream_aux_return(int device, int kind, hipStream_t st);
 inline int fail(goicp_engine* h, int code, const std::string& msg) { if (h) h->err = msg; return code; }
 #define HIPCHK(h, call) do { hipError_t e_ = (call); if (e_ != hipSuccess) return fail(h, GOICP_ERR_HIP, std::string(#call) + ": " + hipGetErrorString(e_)); } while (0)
 // host wait for everything queued on `st` so far
+hipError_t wait_stream_nap(hipStream_t st, int spin_us, int nap_us);      // engine.hip: poll, spinning first and napping afterwards
+hipError_t wait_event_nap(hipEvent_t ev, int spin_us, int nap_us);
 inline hipError_t wait_stream(goicp_engine* h, hipStream_t st) {
+    if (h->hi_shared && st == h->stream_hi) {                             // other engines' small kernels share the stream: wait for our own work only
+        const hipError_t e = hipEventRecord(h->ev_hi, st);
+        if (e != hipSuccess) return e;
+        return h->wait_block == 2 ? wait_event_nap(h->ev_hi, h->wait_spin_us, h->wait_nap_us) : hipEventSynchronize(h->ev_hi);
+    }
+    if (h->wait_block == 2) return wait_stream_nap(st, h->wait_spin_us, h->wait_nap_us);
     if (h->wait_block && h->ev_wait) {
         hipError_t e = hipEventRecord(h->ev_wait, st);
         return e == hipSuccess ? hipEventSynchronize(h->ev_wait) : e;

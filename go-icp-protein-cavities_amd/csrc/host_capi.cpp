@@ -1,4 +1,5 @@
 // host_capi.cpp -- extern "C" wrappers of include/goicp_c.h over the GoICP class and the file pipeline.
+#include <atomic>
 #include <chrono>
 #include <cmath>
 #include <cstring>
@@ -237,12 +238,16 @@ static int finish(GoICP& g, double* res, double t_reg, double t_dt, const double
     return g.status;
 }
 
+static std::atomic<int> g_batch_speculate{-1};
+void goicp_set_batch_speculation(int depth) { g_batch_speculate.store(depth); }
+
 int goicp_run_pair_files(const char* base_dir, const char* target_mol2, const char* source_mol2, int nd_down, const char* config_path,
                          const char* output_path, int pair, int device_id, int verbose, double* res) {
     if (!target_mol2 || !source_mol2 || !config_path || !output_path || !res) return GOICP_ERR_ARG;
     const std::string base = (base_dir && base_dir[0]) ? std::string(base_dir) + "/" : std::string();
     GoICP g;
     g.device_id = device_id; g.verbose = verbose;
+    { const int d = g_batch_speculate.load(); if (d >= 0) g.speculate = d; }                              // what the batch driver chose for its number of registrations in flight
     { const char* e = getenv("GOICP_SPECULATE"); if (e) g.speculate = std::max(0, atoi(e)); }           // experiment knobs of the batch path
     { const char* e = getenv("GOICP_SPEC_POPS"); if (e && atoi(e) > 0) g.spec_pop_budget = (uint32_t)atoi(e); }
     double cfg[18];

@@ -84,6 +84,11 @@ int goicp_get_job_log(goicp_handle*, goicp_bnb_job* jobs, goicp_bnb_result* resu
 int goicp_run_pair_files(const char* base_dir, const char* target_mol2, const char* source_mol2, int nd_downsampled,
                          const char* config_path, const char* output_path, int pair, int device_id, int verbose,
                          double* result24);
+/* How many rotation-queue nodes ahead of the one being expanded goicp_run_pair_files evaluates per launch (GoICP::speculate; process-wide,
+ * -1 = the class default of 128, which suits a registration that has the GPU to itself). A batch that keeps T registrations in flight
+ * shares the GPU between them and does better with less: at T = 14 the configs[3] batch runs at 549 pairs/s with 128, 608 with 16,
+ * 518 with 4. The environment variable GOICP_SPECULATE overrides it. */
+void goicp_set_batch_speculation(int depth);
 /* demo clouds: "N\n x y z\n..." text files (reference demo/model_bunny.txt), no colours / c-FPFH */
 int goicp_run_txt_files(const char* model_txt, const char* data_txt, int nd_downsampled, const char* config_path,
                         const char* output_path, int device_id, int verbose, double* result24);
