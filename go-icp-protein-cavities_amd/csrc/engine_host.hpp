@@ -47,14 +47,10 @@ struct goicp_engine {
 };
 
 
-#define PINNED_BYTES ((size_t)1 << 20)
-hipError_t cache_stream_aux(int device, int kind, hipStream_t* st);
-void cache_stream_aux_return(int device, int kind, hipStream_t st);
+#include "pool.hpp"
 inline int fail(goicp_engine* h, int code, const std::string& msg) { if (h) h->err = msg; return code; }
 #define HIPCHK(h, call) do { hipError_t e_ = (call); if (e_ != hipSuccess) return fail(h, GOICP_ERR_HIP, std::string(#call) + ": " + hipGetErrorString(e_)); } while (0)
 // host wait for everything queued on `st` so far
-hipError_t wait_stream_nap(hipStream_t st, int spin_us, int nap_us);      // engine.hip: poll, spinning first and napping afterwards
-hipError_t wait_event_nap(hipEvent_t ev, int spin_us, int nap_us);
 inline hipError_t wait_stream(goicp_engine* h, hipStream_t st) {
     if (h->hi_shared && st == h->stream_hi) {                             // other engines' small kernels share the stream: wait for our own work only
         const hipError_t e = hipEventRecord(h->ev_hi, st);
@@ -81,7 +77,6 @@ inline hipError_t wait_stream(goicp_engine* h, hipStream_t st) {
     } while (0)
 
 
-hipError_t set_max_dyn_lds(const void* fn);                     // engine.hip: raise a kernel instantiation's dynamic-LDS ceiling once per (device, instantiation)
 inline bool env_is_zero(const char* name) { const char* e = getenv(name); return e && atoi(e) == 0; }
 int ensure_fpscratch(goicp_engine* h, size_t blocks);           // engine.hip
 int ensure_stream_scratch(goicp_engine* h, size_t wgs, bool need_rot, bool need_rows = true);
