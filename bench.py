@@ -425,6 +425,7 @@ def cavity_batch(goicp_amd, args, rank, world, local, use_dist, dist, dev, torch
     if use_dist:
         dist.barrier()
     torch.cuda.synchronize()
+    goicp_amd.batch_search_totals(reset=True)
     t0 = time.perf_counter()
     recs, n_rows = driver.run_batch(base, tsv, cfgp, outd, driver.gpu_register_fn(base, device_id=local), rank=rank, world=world, threads=threads,
                                     dist=dist if use_dist else None)
@@ -433,6 +434,9 @@ def cavity_batch(goicp_amd, args, rank, world, local, use_dist, dist, dev, torch
     t_cav = time.perf_counter() - t0
     if use_dist:
         tt = torch.tensor([t_cav], dtype=torch.float64, device=dev); dist.all_reduce(tt, op=dist.ReduceOp.MAX); t_cav = float(tt.item())
+    tot = goicp_amd.batch_search_totals()             # this rank's registrations of the timed batch
+    search = dict(tot, pops_launched_per_consumed=tot["pops_launched"] / max(1, tot["pops_consumed"]),
+                  jobs_launched_per_consumed=tot["jobs_launched"] / max(1, tot["inner_calls_consumed"]), scope="rank 0's registrations of the timed batch")
     rm = allr[:, 19]
     per_rank = [int((allr[:, 21] == r).sum()) for r in range(world)]
     weak = None
@@ -452,7 +456,7 @@ def cavity_batch(goicp_amd, args, rank, world, local, use_dist, dist, dev, torch
                 concurrent_registrations_per_gpu=threads, host_cores=cores, warmup_pairs=warm, scaling="strong (the whole batch is divided over the ranks)",
                 schedule="longest-first, rows drawn from one shared counter" if world > 1 else "longest-first", pairs_per_rank=per_rank,
                 failed=int((allr[:, 20] != 0).sum()), rmsd_gathered=int((~np.isnan(rm)).sum()), rmsd_median=float(np.nanmedian(rm)), rmsd_below_2A=int((rm < 2.0).sum()),
-                rank0_seconds_before_gather=t_local, weak=weak,
+                rank0_seconds_before_gather=t_local, search=search, weak=weak,
                 config="BASELINE configs[3]: rows 1-2 shipped cavity pairs, rows 3-%d seeded synthetic cavity-like pairs (N in [150,400]); shipped config.txt + cfpfh=1, regularizationFPFH=5e-6; file pipeline incl. protein transform + RMSD" % args.cavity_rows,
                 _base=base, _tsv=tsv, _cfg=cfgp)
 

@@ -378,6 +378,14 @@ def set_batch_speculation(depth):
     load_library().goicp_set_batch_speculation(int(depth))
 
 
+def batch_search_totals(reset=False):
+    """Totals of the run_pair_files calls of this process (include/goicp_c.h: goicp_batch_search_totals)."""
+    out = np.zeros(6, np.uint64)
+    load_library().goicp_batch_search_totals(out.ctypes.data_as(C.c_void_p), int(bool(reset)))
+    keys = ("registrations", "pops_launched", "pops_consumed", "jobs_launched", "inner_calls_consumed", "launches")
+    return {k: int(v) for k, v in zip(keys, out)}
+
+
 def run_pair_files(base_dir, target_mol2, source_mol2, nd, config, output, pair, device_id=0, verbose=0):
     """The reference's main() on files (argv order of reference README.md:17)."""
     L = load_library()

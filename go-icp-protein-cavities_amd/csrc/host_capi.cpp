@@ -241,6 +241,16 @@ static int finish(GoICP& g, double* res, double t_reg, double t_dt, const double
 static std::atomic<int> g_batch_speculate{-1};
 void goicp_set_batch_speculation(int depth) { g_batch_speculate.store(depth); }
 
+// what the file pipeline's registrations of this process launched and what their replays consumed (speculation cost of a batch)
+static std::atomic<uint64_t> g_tot[6];
+static void add_totals(const GoICP& g) {
+    const uint64_t v[6] = {1, g.stats.pops_launched, g.stats.trans_pops, g.stats.inner_jobs_launched, g.stats.inner_calls, g.stats.inner_launches};
+    for (int k = 0; k < 6; k++) g_tot[k].fetch_add(v[k], std::memory_order_relaxed);
+}
+void goicp_batch_search_totals(uint64_t* out6, int reset) {
+    for (int k = 0; k < 6; k++) { const uint64_t v = reset ? g_tot[k].exchange(0, std::memory_order_relaxed) : g_tot[k].load(std::memory_order_relaxed); if (out6) out6[k] = v; }
+}
+
 int goicp_run_pair_files(const char* base_dir, const char* target_mol2, const char* source_mol2, int nd_down, const char* config_path,
                          const char* output_path, int pair, int device_id, int verbose, double* res) {
     if (!target_mol2 || !source_mol2 || !config_path || !output_path || !res) return GOICP_ERR_ARG;
@@ -282,6 +292,7 @@ int goicp_run_pair_files(const char* base_dir, const char* target_mol2, const ch
         rescaled_translation(g, scale, smean, tmean, resc);
         write_rescaled(rescaled_name(output_path), t_reg, g, resc);
     } else if (verbose) std::cerr << "goicp: " << g.error_message << std::endl;
+    add_totals(g);
     return finish(g, res, t_reg, t_dt, resc);
 }
 

@@ -581,7 +581,7 @@ float GoICP::InnerBnB(const float* R9, int rot_level, TRANSNODE* out) {
     goicp_bnb_job j = make_job(R9, rot_level, optError, SSEThresh, initNodeTrans);
     goicp_bnb_result r;
     status = goicp_engine_inner_bnb(eng_, &j, &r);
-    stats.inner_calls++; stats.inner_launches++; stats.inner_jobs_launched++; stats.cube_evals += r.cube_evals; stats.trans_pops += r.pops;
+    stats.inner_calls++; stats.inner_launches++; stats.inner_jobs_launched++; stats.cube_evals += r.cube_evals; stats.trans_pops += r.pops; stats.pops_launched += r.pops;
     if (out && r.found) { out->x = r.node[0]; out->y = r.node[1]; out->z = r.node[2]; out->w = r.node[3]; }
     return r.optErrorT;
 }

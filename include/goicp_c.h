@@ -89,6 +89,11 @@ int goicp_run_pair_files(const char* base_dir, const char* target_mol2, const ch
  * shares the GPU between them and does better with less: at T = 14 the configs[3] batch runs at 549 pairs/s with 128, 608 with 16,
  * 518 with 4. The environment variable GOICP_SPECULATE overrides it. */
 void goicp_set_batch_speculation(int depth);
+/* Totals over the goicp_run_pair_files calls of this process since the last reset (any host thread): out6 = registrations, translation-queue
+ * pops LAUNCHED (of every search job sent to the device, consumed by the replay or not), pops CONSUMED (the reference's own pop count,
+ * jly_goicp.cpp:297-333), search jobs launched, InnerBnB calls consumed (jly_goicp.cpp:706,810), launches. launched / consumed is what the
+ * speculation of a batch costs. */
+void goicp_batch_search_totals(uint64_t* out6, int reset);
 /* demo clouds: "N\n x y z\n..." text files (reference demo/model_bunny.txt), no colours / c-FPFH */
 int goicp_run_txt_files(const char* model_txt, const char* data_txt, int nd_downsampled, const char* config_path,
                         const char* output_path, int device_id, int verbose, double* result24);

@@ -602,7 +602,11 @@ def test_file_pipeline_reproduces_shipped_output_files(tmp_path):
         os.remove(os.path.join(base, "cavitiesN", f))
     cfgp = os.path.join(base, "config.txt"); _default_config_file(cfgp)
     outp = os.path.join(base, "output", "out1.txt")
+    goicp_amd.batch_search_totals(reset=True)
     res = goicp_amd.run_pair_files(base, "cavities/1eq2_6_cavity6.mol2", "cavities/2x86_3_cavity6.mol2", 238, cfgp, outp, 1)
+    tot = goicp_amd.batch_search_totals()       # process-wide totals of the file pipeline: one registration, its consumed pops among the launched ones
+    assert tot["registrations"] == 1 and tot["pops_consumed"] == res["trans_pops"] > 0
+    assert tot["pops_launched"] >= tot["pops_consumed"] and tot["jobs_launched"] >= tot["inner_calls_consumed"] > 0
     got = open(outp).read().splitlines(); want = open(os.path.join(data, "output", "similar1.txt")).read().splitlines()
     assert got[0].startswith("Time: ") and got[1:] == want[1:]
     got = open(outp.replace(".txt", "_rescaled.txt")).read().splitlines()
