@@ -115,7 +115,11 @@ def main():
     use_dist = world > 1 or ("RANK" in os.environ and "MASTER_PORT" in os.environ)
     if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl")       # RCCL on ROCm
+        # RCCL on ROCm. Rehearsal of the N > 1 path on a ONE-GPU box (never the measured configuration): GOICP_BENCH_BACKEND=gloo with
+        # GOICP_BENCH_ONE_GPU=1 puts every rank on device 0 (RCCL refuses two ranks on one device); the JSON line then says so in `rehearsal`.
+        dist.init_process_group(os.environ.get("GOICP_BENCH_BACKEND", "nccl"))
+    if os.environ.get("GOICP_BENCH_ONE_GPU") == "1":
+        local = 0
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
 
@@ -316,6 +320,9 @@ def main():
             "cavity_batch": cav,
             "stress": stress,
         }
+        if os.environ.get("GOICP_BENCH_ONE_GPU") == "1" or os.environ.get("GOICP_BENCH_BACKEND", "nccl") != "nccl":
+            line["rehearsal"] = "NOT a measurement: %d ranks, backend %s, GOICP_BENCH_ONE_GPU=%s (all ranks share device 0)" % (
+                world, os.environ.get("GOICP_BENCH_BACKEND", "nccl"), os.environ.get("GOICP_BENCH_ONE_GPU", "0"))
         print(json.dumps(line))
     if use_dist:
         dist.barrier()
@@ -430,7 +437,7 @@ def cavity_batch(goicp_amd, args, rank, world, local, use_dist, dist, dev, torch
     recs, n_rows = driver.run_batch(base, tsv, cfgp, outd, driver.gpu_register_fn(base, device_id=local), rank=rank, world=world, threads=threads,
                                     dist=dist if use_dist else None)
     t_local = time.perf_counter() - t0
-    allr = driver.gather_records(recs, n_rows, dist=dist if use_dist else None, device=dev if use_dist else None)   # THE exchange: one all_gather (RCCL)
+    allr = driver.gather_records(recs, n_rows, dist=dist if use_dist else None, device=dev if use_dist and dist.get_backend() == "nccl" else None)   # THE exchange: one all_gather (RCCL; host tensors under the gloo rehearsal)
     t_cav = time.perf_counter() - t0
     if use_dist:
         tt = torch.tensor([t_cav], dtype=torch.float64, device=dev); dist.all_reduce(tt, op=dist.ReduceOp.MAX); t_cav = float(tt.item())
