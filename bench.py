@@ -439,8 +439,10 @@ def cavity_batch(goicp_amd, args, rank, world, local, use_dist, dist, dev, torch
     t_local = time.perf_counter() - t0
     allr = driver.gather_records(recs, n_rows, dist=dist if use_dist else None, device=dev if use_dist and dist.get_backend() == "nccl" else None)   # THE exchange: one all_gather (RCCL; host tensors under the gloo rehearsal)
     t_cav = time.perf_counter() - t0
+    t_ranks = [t_local]
     if use_dist:
         tt = torch.tensor([t_cav], dtype=torch.float64, device=dev); dist.all_reduce(tt, op=dist.ReduceOp.MAX); t_cav = float(tt.item())
+        t_ranks = [None] * world; dist.all_gather_object(t_ranks, t_local)       # (after the timed region: how long each rank registered before the gather)
     tot = goicp_amd.batch_search_totals()             # this rank's registrations of the timed batch
     search = dict(tot, pops_launched_per_consumed=tot["pops_launched"] / max(1, tot["pops_consumed"]),
                   jobs_launched_per_consumed=tot["jobs_launched"] / max(1, tot["inner_calls_consumed"]), scope="rank 0's registrations of the timed batch")
@@ -455,15 +457,17 @@ def cavity_batch(goicp_amd, args, rank, world, local, use_dist, dist, dev, torch
         dist.barrier(); torch.cuda.synchronize()
         t0 = time.perf_counter()
         wrecs, _ = driver.run_batch(wbase, wtsv, wcfg, os.path.join(wbase, "output"), driver.gpu_register_fn(wbase, device_id=local), rank=0, world=1, threads=threads, rmsd=False)
-        tw = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=dev); dist.all_reduce(tw, op=dist.ReduceOp.MAX)
+        t_weak_local = time.perf_counter() - t0
+        tw = torch.tensor([t_weak_local], dtype=torch.float64, device=dev); dist.all_reduce(tw, op=dist.ReduceOp.MAX)
         nw = torch.tensor([float(len(wrecs))], dtype=torch.float64, device=dev); dist.all_reduce(nw, op=dist.ReduceOp.SUM)
+        tw_ranks = [None] * world; dist.all_gather_object(tw_ranks, t_weak_local)
         weak = dict(pairs=int(nw.item()), seconds=float(tw.item()), cavity_pair_registrations_per_sec=float(nw.item()) / float(tw.item()),
-                    scaling="weak (every rank registers all %d rows)" % args.cavity_rows)
+                    scaling="weak (every rank registers all %d rows)" % args.cavity_rows, seconds_per_rank=[float(x) for x in tw_ranks])
     return dict(pairs=int(allr.shape[0]), seconds=t_cav, cavity_pair_registrations_per_sec=allr.shape[0] / t_cav, cube_evals=int(np.nansum(allr[:, 18])),
                 concurrent_registrations_per_gpu=threads, host_cores=cores, warmup_pairs=warm, scaling="strong (the whole batch is divided over the ranks)",
                 schedule="longest-first, rows drawn from one shared counter" if world > 1 else "longest-first", pairs_per_rank=per_rank,
                 failed=int((allr[:, 20] != 0).sum()), rmsd_gathered=int((~np.isnan(rm)).sum()), rmsd_median=float(np.nanmedian(rm)), rmsd_below_2A=int((rm < 2.0).sum()),
-                rank0_seconds_before_gather=t_local, search=search, weak=weak,
+                rank0_seconds_before_gather=t_local, seconds_before_gather_per_rank=[float(x) for x in t_ranks], search=search, weak=weak,
                 config="BASELINE configs[3]: rows 1-2 shipped cavity pairs, rows 3-%d seeded synthetic cavity-like pairs (N in [150,400]); shipped config.txt + cfpfh=1, regularizationFPFH=5e-6; file pipeline incl. protein transform + RMSD" % args.cavity_rows,
                 _base=base, _tsv=tsv, _cfg=cfgp)
 
