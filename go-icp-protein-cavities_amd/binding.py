@@ -335,6 +335,13 @@ class GoICP:
         self.L.goicp_icp_distances(self.h, _ptr(dis))
         return np.float32(e), R.reshape(3, 3), t, corr, dis
 
+    def stats(self):
+        """Counters of this handle so far (goicp_get_stats): rotation pops, InnerBnB calls / launches / jobs, cube evaluations, queue pops, ICP calls / iterations."""
+        st = np.zeros(8, np.uint64); ms = C.c_double()
+        self.L.goicp_get_stats(self.h, _ptr(st), C.byref(ms))
+        keys = ["rot_pops", "inner_calls", "inner_launches", "inner_jobs_launched", "cube_evals", "trans_pops", "icp_calls", "icp_iters"]
+        return dict(zip(keys, [int(v) for v in st]))
+
     def record_jobs(self, on=True):
         self.L.goicp_record_jobs(self.h, 1 if on else 0)
 

@@ -205,7 +205,7 @@ __global__ __launch_bounds__(256) void k_icp_nn_slab(DevTables T, const float* _
 // host_kdorder.hpp): the kernel returns the state before that iteration with status 1 and the host loop carries on from it.
 // ---------------------------------------------------------------------------------------------
 struct IcpState { double R[9], t[3], mu_m[3], mu_d[3]; float err, err_new; int iters, status; };
-__global__ __launch_bounds__(1024) void k_icp_loop(DevTables T, const float* __restrict__ mxyz, IcpState st0, float err_diff, int max_iters,
+__global__ __launch_bounds__(1024) void k_icp_loop(DevTables T, const float* __restrict__ mxyz, IcpState st0, float err_diff, int max_iters, int trim_num,
                                                     IcpState* __restrict__ st_out, int* __restrict__ ids_out, float* __restrict__ dsq_out) {
     extern __shared__ float icp_lds[];
     const int n = T.Nd, Nm = T.Nm, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, NWV = blockDim.x >> 6;
@@ -218,6 +218,14 @@ __global__ __launch_bounds__(1024) void k_icp_loop(DevTables T, const float* __r
     float* pbest = dx + 3 * n;            // [parts * n] partial searches: closest distance, its lowest index, how many points sit at it
     int* pidx = reinterpret_cast<int*>(pbest + 1024);
     int* pcnt = pidx + 1024;
+    // trimmed runs (trim_num > 0; jly_icp3d.hpp:254-262): the sums run over the trim_num closest points in the order of the reference's sort by distance --
+    // qsort under a comparator without equality = glibc's stable merge sort = ascending (distance, data index). Sorted copies live behind the rest.
+    const bool trimmed = trim_num > 0;
+    const int cnt_sum = trimmed ? trim_num : n;
+    float* pd2 = reinterpret_cast<float*>(pcnt + 1024);   // [3 n] pd in sorted order   (allocated only for trimmed runs)
+    float* pm2 = pd2 + 3 * n;                             // [3 n] pm in sorted order
+    float* dsq2 = pm2 + 3 * n;                            // [n]   distances, ascending
+    const float* spd = trimmed ? pd2 : pd; const float* spm = trimmed ? pm2 : pm; const float* sdsq = trimmed ? dsq2 : dsq;
     __shared__ double sR[9], st[3], smu_m[3], smu_d[3], sH[9];
     __shared__ float serr, serr_new;
     __shared__ int sties, sstop;
@@ -290,51 +298,63 @@ __global__ __launch_bounds__(1024) void k_icp_loop(DevTables T, const float* __r
         __syncthreads();
         ISTAMP(0);
         if (sties) { status = 1; iters--; break; }            // this iteration belongs to the host (kd-tree order among tied model points)
+        if (trimmed) {
+            // rank of point i = points that sort before it; the keys (distance, index) are distinct, so the ranks are a permutation
+            if (tid < n) {
+                const float di = dsq[tid];
+                int r = 0;
+                for (int j = 0; j < n; j++) { const float dj = dsq[j]; r += (dj < di || (dj == di && j < tid)) ? 1 : 0; }      // (all lanes read the same word: broadcast)
+                pd2[3 * r] = pd[3 * tid]; pd2[3 * r + 1] = pd[3 * tid + 1]; pd2[3 * r + 2] = pd[3 * tid + 2];
+                pm2[3 * r] = pm[3 * tid]; pm2[3 * r + 1] = pm[3 * tid + 1]; pm2[3 * r + 2] = pm[3 * tid + 2];
+                dsq2[r] = di;
+            }
+            __syncthreads();
+        }
         // ---- the seven running sums, each sequential over the point index on a lane of its own (jly_icp3d.hpp:256-276)
         if (tid < 6) {
-            const float* src = tid < 3 ? pm + tid : pd + (tid - 3);
+            const float* src = tid < 3 ? spm + tid : spd + (tid - 3);
             double acc = tid < 3 ? smu_m[tid] : smu_d[tid - 3];
             int i = 0;
-            for (; i + 32 <= n; i += 32) {                     // 32 reads in flight, then the 32 dependent adds
+            for (; i + 32 <= cnt_sum; i += 32) {                     // 32 reads in flight, then the 32 dependent adds
                 float v[32];
 #pragma unroll
                 for (int q = 0; q < 32; q++) v[q] = src[3 * (i + q)];
 #pragma unroll
                 for (int q = 0; q < 32; q++) acc += (double)v[q];
             }
-            for (; i + 8 <= n; i += 8) {
+            for (; i + 8 <= cnt_sum; i += 8) {
                 float v[8];
 #pragma unroll
                 for (int q = 0; q < 8; q++) v[q] = src[3 * (i + q)];
 #pragma unroll
                 for (int q = 0; q < 8; q++) acc += (double)v[q];
             }
-            for (; i < n; i++) acc += (double)src[3 * i];
+            for (; i < cnt_sum; i++) acc += (double)src[3 * i];
             if (tid < 3) smu_m[tid] = acc; else smu_d[tid - 3] = acc;
         } else if (tid == 6) {
             float e = 0.f;
             int i = 0;
-            for (; i + 32 <= n; i += 32) {
+            for (; i + 32 <= cnt_sum; i += 32) {
                 float v[32];
 #pragma unroll
-                for (int q = 0; q < 32; q++) v[q] = dsq[i + q];
+                for (int q = 0; q < 32; q++) v[q] = sdsq[i + q];
 #pragma unroll
                 for (int q = 0; q < 32; q++) e = (float)((double)e + (double)v[q]);
             }
-            for (; i + 8 <= n; i += 8) {
+            for (; i + 8 <= cnt_sum; i += 8) {
                 float v[8];
 #pragma unroll
-                for (int q = 0; q < 8; q++) v[q] = dsq[i + q];
+                for (int q = 0; q < 8; q++) v[q] = sdsq[i + q];
 #pragma unroll
                 for (int q = 0; q < 8; q++) e = (float)((double)e + (double)v[q]);
             }
-            for (; i < n; i++) e = (float)((double)e + (double)dsq[i]);
+            for (; i < cnt_sum; i++) e = (float)((double)e + (double)sdsq[i]);
             serr_new = e;
         }
         __syncthreads();
         if (tid == 0) {
             const float err = serr, err_new = serr_new;
-            if (err > 0 && err - err_new < err_diff * n) sstop = 1;            // jly_icp3d.hpp:272 (num = n: untrimmed)
+            if (err > 0 && err - err_new < err_diff * cnt_sum) sstop = 1;      // jly_icp3d.hpp:272 (num points in the sums; the means below still divide by n)
             else {
                 serr = err_new;
                 for (int k = 0; k < 3; k++) { smu_m[k] = smu_m[k] / (double)(float)n; smu_d[k] = smu_d[k] / (double)(float)n; }
@@ -349,24 +369,24 @@ __global__ __launch_bounds__(1024) void k_icp_loop(DevTables T, const float* __r
             const double ma = smu_d[a], mb = smu_m[b];
             double acc = 0;
             int i = 0;
-            for (; i + 16 <= n; i += 16) {                     // 32 reads in flight; the products do not wait for the running sum
+            for (; i + 16 <= cnt_sum; i += 16) {                     // 32 reads in flight; the products do not wait for the running sum
                 float va[16], vb[16];
 #pragma unroll
-                for (int q = 0; q < 16; q++) { va[q] = pd[3 * (i + q) + a]; vb[q] = pm[3 * (i + q) + b]; }
+                for (int q = 0; q < 16; q++) { va[q] = spd[3 * (i + q) + a]; vb[q] = spm[3 * (i + q) + b]; }
                 double pr[16];
 #pragma unroll
                 for (int q = 0; q < 16; q++) pr[q] = ((double)va[q] - ma) * ((double)vb[q] - mb);
 #pragma unroll
                 for (int q = 0; q < 16; q++) acc += pr[q];
             }
-            for (; i + 8 <= n; i += 8) {
+            for (; i + 8 <= cnt_sum; i += 8) {
                 float va[8], vb[8];
 #pragma unroll
-                for (int q = 0; q < 8; q++) { va[q] = pd[3 * (i + q) + a]; vb[q] = pm[3 * (i + q) + b]; }
+                for (int q = 0; q < 8; q++) { va[q] = spd[3 * (i + q) + a]; vb[q] = spm[3 * (i + q) + b]; }
 #pragma unroll
                 for (int q = 0; q < 8; q++) acc += ((double)va[q] - ma) * ((double)vb[q] - mb);
             }
-            for (; i < n; i++) acc += ((double)pd[3 * i + a] - ma) * ((double)pm[3 * i + b] - mb);
+            for (; i < cnt_sum; i++) acc += ((double)spd[3 * i + a] - ma) * ((double)spm[3 * i + b] - mb);
             sH[tid] = acc;
         }
         __syncthreads();
@@ -1005,23 +1025,32 @@ extern "C" int goicp_engine_icp_nn_ties(goicp_engine* h, const double* R9, const
 }
 
 static_assert(sizeof(IcpState) == sizeof(goicp_icp_state), "goicp_icp_state");
-extern "C" int goicp_engine_icp_loop(goicp_engine* h, goicp_icp_state* state, float err_diff, int max_iters, int32_t* id_model, float* dist_sq) {
+static int icp_loop_impl(goicp_engine* h, goicp_icp_state* state, float err_diff, int max_iters, int trim_num, int32_t* id_model, float* dist_sq) {
     if (!h || !state || !id_model || !dist_sq || max_iters < 0) return GOICP_ERR_ARG;
     const size_t n = (size_t)h->T.Nd, nm = (size_t)h->T.Nm;
-    const size_t lds = (3 * nm + 11 * n + 3 * 1024) * sizeof(float);
-    // cavity class only: untrimmed, everything in one workgroup's LDS, results through the pinned buffer
-    if (h->T.doTrim || h->T.Nm <= 0 || n > 1024 || nm > 2048 || lds > 120 * 1024 || !h->pinned || sizeof(IcpState) + 8 * n + 64 > PINNED_BYTES) return GOICP_ERR_ARG;
+    if (trim_num < 0 || (size_t)trim_num > n) return GOICP_ERR_ARG;
+    const size_t lds = (3 * nm + (trim_num > 0 ? 18 : 11) * n + 3 * 1024) * sizeof(float);
+    // cavity class only: everything in one workgroup's LDS, results through the pinned buffer
+    if (h->T.Nm <= 0 || n > 1024 || nm > 2048 || lds > 120 * 1024 || !h->pinned || sizeof(IcpState) + 8 * n + 64 > PINNED_BYTES) return GOICP_ERR_ARG;
     HIPCHK(h, hipSetDevice(h->device));
     if (lds > 48 * 1024) HIPCHK(h, set_max_dyn_lds(reinterpret_cast<const void*>(&k_icp_loop)));
     IcpState st0; memcpy(&st0, state, sizeof st0);
     IcpState* po = (IcpState*)h->pinned;
     int* pid = (int*)((char*)h->pinned + ((sizeof(IcpState) + 63) & ~(size_t)63)); float* pdq = (float*)(pid + n);
-    hipLaunchKernelGGL(k_icp_loop, dim3(1), dim3(1024), lds, h->stream_hi, h->T, h->d_mxyz, st0, err_diff, max_iters, po, pid, pdq);
+    hipLaunchKernelGGL(k_icp_loop, dim3(1), dim3(1024), lds, h->stream_hi, h->T, h->d_mxyz, st0, err_diff, max_iters, trim_num, po, pid, pdq);
     HIPCHK(h, hipGetLastError());
     HIPCHK(h, wait_stream(h, h->stream_hi));
     memcpy(state, po, sizeof st0);
     memcpy(id_model, pid, n * sizeof(int)); memcpy(dist_sq, pdq, n * sizeof(float));
     return GOICP_OK;
+}
+extern "C" int goicp_engine_icp_loop(goicp_engine* h, goicp_icp_state* state, float err_diff, int max_iters, int32_t* id_model, float* dist_sq) {
+    if (h && h->T.doTrim) return GOICP_ERR_ARG;               // a trimmed engine iterates over its closest points: goicp_engine_icp_loop_trimmed
+    return icp_loop_impl(h, state, err_diff, max_iters, 0, id_model, dist_sq);
+}
+extern "C" int goicp_engine_icp_loop_trimmed(goicp_engine* h, goicp_icp_state* state, float err_diff, int max_iters, int num, int32_t* id_model, float* dist_sq) {
+    if (num <= 0) return GOICP_ERR_ARG;
+    return icp_loop_impl(h, state, err_diff, max_iters, num, id_model, dist_sq);
 }
 
 extern "C" int goicp_engine_icp_nn(goicp_engine* h, const double* R9, const double* t3, int32_t* id_model, float* dist_sq) {

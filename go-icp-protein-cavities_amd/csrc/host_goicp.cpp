@@ -408,20 +408,50 @@ float GoICP::icp_run(Matrix& R, Matrix& t) {
     auto pack_in_index_order = [&]() {
         for (int i = 0; i < n; i++) { uint32_t k; std::memcpy(&k, &dsq[i], 4); ka[i] = ((uint64_t)k << 32) | (uint32_t)i; }
     };
-    if (!doTrim && device_icp) {
-        // cavity-sized untrimmed clouds: the whole loop in one launch (k_icp_loop: same sums in the same order, same 3x3 algebra). It hands
-        // back early only at an iteration with an exact distance tie between model points, which the kd-tree order below decides.
+    auto pack_sorted = [&]() {
+        // qsort with a comparator that never reports equality (jly_icp3d.hpp:172-176,254); under glibc's merge sort ties keep
+        // their order, i.e. a stable sort by dis = the numeric order of the packed words (unique, so any sorting method gives it).
+        // Two stable counting passes over key bits 10-20 and 21-31 (one read builds both histograms), then an insertion pass on the
+        // whole words for the low 10 key bits: runs of equal upper bits are short, and exact ties are already in index order. A cloud
+        // that defeats this (thousands of distinct distances inside one 2^-13 relative band) goes to std::sort after 16 n moves.
+        uint32_t cnt[2][2048];
+        std::memset(cnt, 0, sizeof cnt);
+        for (int i = 0; i < n; i++) {
+            uint32_t k; std::memcpy(&k, &dsq[i], 4);
+            ka[i] = ((uint64_t)k << 32) | (uint32_t)i; cnt[0][(k >> 10) & 2047u]++; cnt[1][k >> 21]++;
+        }
+        for (int p = 0; p < 2; p++) {
+            uint32_t run = 0;
+            for (int b = 0; b < 2048; b++) { const uint32_t c = cnt[p][b]; cnt[p][b] = run; run += c; }
+            const int sh = 42 + 11 * p;
+            for (int i = 0; i < n; i++) { const uint64_t v = ka[i]; kb[cnt[p][(uint32_t)(v >> sh) & 2047u]++] = v; }
+            ka.swap(kb);
+        }
+        long moves = 0; const long budget = 16L * n;
+        int i = 1;
+        for (; i < n && moves <= budget; i++) {
+            const uint64_t v = ka[i]; int j = i - 1;
+            while (j >= 0 && ka[j] > v) { ka[j + 1] = ka[j]; j--; }
+            ka[j + 1] = v; moves += i - 1 - j;
+        }
+        if (i < n) std::sort(ka.begin(), ka.end());
+    };
+    if (device_icp) {
+        // cavity-sized clouds: the whole loop in one launch (k_icp_loop: same sums in the same order -- for trimmed runs the order of the sort by
+        // distance --, same 3x3 algebra). It hands back early only at an iteration with an exact distance tie between model points, which the
+        // kd-tree order below decides.
         goicp_icp_state S;
         std::memcpy(S.R, Rd, sizeof Rd); std::memcpy(S.t, td, sizeof td);
         for (int k = 0; k < 3; k++) { S.mu_m[k] = 0; S.mu_d[k] = 0; }
         S.err = err; S.err_new = err_new; S.iters = 0; S.status = 0;
-        const int rc = goicp_engine_icp_loop(eng_, &S, err_diff, 10000, ids.data(), dsq.data());
+        const int rc = doTrim ? goicp_engine_icp_loop_trimmed(eng_, &S, err_diff, 10000, num, ids.data(), dsq.data())
+                              : goicp_engine_icp_loop(eng_, &S, err_diff, 10000, ids.data(), dsq.data());
         if (rc == GOICP_OK) {
             stats.icp_iters += (uint64_t)S.iters; iter = (size_t)S.iters;
             std::memcpy(Rd, S.R, sizeof Rd); std::memcpy(td, S.t, sizeof td);
             for (int k = 0; k < 3; k++) { mu_m[k] = S.mu_m[k]; mu_d[k] = S.mu_d[k]; }
             err = S.err; err_new = S.err_new;
-            if (S.status != 1) { pack_in_index_order(); finished = true; }
+            if (S.status != 1) { if (doTrim) pack_sorted(); else pack_in_index_order(); finished = true; }
         } else if (rc != GOICP_ERR_ARG) { status = rc; return std::numeric_limits<float>::quiet_NaN(); }
     }
     for (; !finished && iter < 10000; iter++) {
@@ -440,35 +470,7 @@ float GoICP::icp_run(Matrix& R, Matrix& t) {
             const float q[3] = {r00 * x + r01 * y + r02 * z + t0, r10 * x + r11 * y + r12 * z + t1, r20 * x + r21 * y + r22 * z + t2};   // jly_icp3d.hpp:239-241
             ids[i] = kd_order_.nearest(q);
         }
-        if (!doTrim) pack_in_index_order();
-        else {
-            // qsort with a comparator that never reports equality (jly_icp3d.hpp:172-176,254); under glibc's merge sort ties keep
-            // their order, i.e. a stable sort by dis = the numeric order of the packed words (unique, so any sorting method gives it).
-            // Two stable counting passes over key bits 10-20 and 21-31 (one read builds both histograms), then an insertion pass on the
-            // whole words for the low 10 key bits: runs of equal upper bits are short, and exact ties are already in index order. A cloud
-            // that defeats this (thousands of distinct distances inside one 2^-13 relative band) goes to std::sort after 16 n moves.
-            uint32_t cnt[2][2048];
-            std::memset(cnt, 0, sizeof cnt);
-            for (int i = 0; i < n; i++) {
-                uint32_t k; std::memcpy(&k, &dsq[i], 4);
-                ka[i] = ((uint64_t)k << 32) | (uint32_t)i; cnt[0][(k >> 10) & 2047u]++; cnt[1][k >> 21]++;
-            }
-            for (int p = 0; p < 2; p++) {
-                uint32_t run = 0;
-                for (int b = 0; b < 2048; b++) { const uint32_t c = cnt[p][b]; cnt[p][b] = run; run += c; }
-                const int sh = 42 + 11 * p;
-                for (int i = 0; i < n; i++) { const uint64_t v = ka[i]; kb[cnt[p][(uint32_t)(v >> sh) & 2047u]++] = v; }
-                ka.swap(kb);
-            }
-            long moves = 0; const long budget = 16L * n;
-            int i = 1;
-            for (; i < n && moves <= budget; i++) {
-                const uint64_t v = ka[i]; int j = i - 1;
-                while (j >= 0 && ka[j] > v) { ka[j + 1] = ka[j]; j--; }
-                ka[j + 1] = v; moves += i - 1 - j;
-            }
-            if (i < n) std::sort(ka.begin(), ka.end());
-        }
+        if (!doTrim) pack_in_index_order(); else pack_sorted();
         err_new = 0;
         for (int i = 0; i < num; i++) {
             const uint64_t v = ka[i];

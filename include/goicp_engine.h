@@ -173,6 +173,11 @@ int goicp_engine_icp_nn_ties(goicp_engine* h, const double* R9, const double* t3
  * GOICP_ERR_ARG when the configuration is outside the above (the caller then iterates with goicp_engine_icp_nn_ties). */
 typedef struct { double R[9], t[3], mu_m[3], mu_d[3]; float err, err_new; int32_t iters, status; } goicp_icp_state;
 int goicp_engine_icp_loop(goicp_engine* h, goicp_icp_state* state, float err_diff, int max_iters, int32_t* id_model, float* dist_sq);
+/* The same for TRIMMED runs (reference jly_icp3d.hpp:254-262): every iteration orders the points by (squared distance, data index) -- the order
+ * the reference's qsort leaves under its comparator without equality -- and takes the error sum, the centroids and the cross-covariance over
+ * the first `num` = (int)(Nd * (1 - trimFraction)) of them, sequentially in that order; the centroids are still divided by Nd and the stop test
+ * uses `num`. id_model / dist_sq come back by data index, as above. */
+int goicp_engine_icp_loop_trimmed(goicp_engine* h, goicp_icp_state* state, float err_diff, int max_iters, int num, int32_t* id_model, float* dist_sq);
 
 int goicp_engine_synchronize(goicp_engine* h);
 /* cumulative counters since create: cube evaluations, point lookups, kernel milliseconds (HIP events) */

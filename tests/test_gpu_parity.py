@@ -190,6 +190,40 @@ def test_icp_against_reference_fixtures(name):
     g.close()
 
 
+@pytest.mark.parametrize("nd,nm,trim,dup", [(97, 300, 0.1, False), (238, 238, 0.3, False), (777, 1500, 0.05, True), (1024, 2048, 0.2, False),
+                                            (1024, 1024, 0.9, True)])
+def test_trimmed_icp_in_one_launch_equals_the_host_loop(monkeypatch, nd, nm, trim, dup):
+    """ICP3D::Run on trimmed cavity-sized clouds (reference jly_icp3d.hpp:254-262) as ONE launch (goicp_engine_icp_loop_trimmed: the sort by
+    distance as ranks in LDS, sums over the closest points in that order) against the host loop that launches one search per iteration and is
+    pinned to the compiled reference by the fixtures above: error, R, t, correspondences (in sorted order) and distances bit for bit, from
+    several start poses; sizes up to the LDS limit of the kernel (1024 data / 2048 model points); `dup` plants equal distances (duplicated
+    data points: equal keys except for the index, the stable order decides) and duplicated model points (exact ties: the hand-back path)."""
+    P = synth_pair(max(nd, nm), seed=5150 + nd, noise=0.01, outlier_frac=0.1, theta_range=(0.1, 0.5))
+    model = P["t"][:nm].copy(); data = P["s"][:nd].copy()
+    if dup:
+        data[nd // 2:nd // 2 + 40] = data[:40]
+        model[nm // 2:nm // 2 + 25] = model[:25]
+    cfg = goicp_amd.cfg_vector(trimFraction=trim, regularization=0.0, regularizationFPFH=0.0, cfpfh=0, ponderation=0, distTransSize=50)
+    rng = np.random.default_rng(nd)
+    poses = []
+    for _ in range(4):
+        aa = rng.normal(size=3); aa *= rng.uniform(0.0, 0.6) / np.linalg.norm(aa)
+        th = np.linalg.norm(aa); k = aa / th
+        K = np.array([[0, -k[2], k[1]], [k[2], 0, -k[0]], [-k[1], k[0], 0]])
+        poses.append((np.eye(3) + np.sin(th) * K + (1 - np.cos(th)) * K @ K, rng.uniform(-0.1, 0.1, 3)))
+    out = {}
+    for mode in ("1", "0"):
+        monkeypatch.setenv("GOICP_DEVICE_ICP", mode)
+        g = goicp_amd.GoICP(cfg); g.set_clouds(model, data); g.build_dt(); g.initialize()
+        out[mode] = [g.icp(R, t) for R, t in poses]
+        out[mode + "_iters"] = g.stats()["icp_iters"]
+        g.close()
+    assert out["1_iters"] == out["0_iters"] > 4
+    for a, b in zip(out["1"], out["0"]):
+        assert a[0] == b[0] and np.array_equal(a[1], b[1]) and np.array_equal(a[2], b[2])
+        assert np.array_equal(a[3], b[3]) and np.array_equal(a[4], b[4])
+
+
 @pytest.mark.parametrize("name", ["plain", "trim", "geo"])
 def test_icp_tie_rule_against_reference_fixture(name):
     """Exact distance ties (duplicated model points, lattice-midpoint queries): the device search reports them and the host
