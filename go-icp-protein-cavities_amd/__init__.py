@@ -9,7 +9,7 @@ The directory name is not a Python identifier; load it with
 or `import goicp_amd` (the alias module at the repository root).
 """
 from .binding import (LIB_PATH, lib, load_library, Engine, GoICP, EngineError, CFG_KEYS, DEFAULT_CFG, cfg_vector,  # noqa: F401
-                      GOICP_OK, run_pair_files, run_txt_files, compute_rmsd, apply_transformation_protein, batch_search_totals, set_batch_speculation)
+                      GOICP_OK, run_pair_files, run_txt_files, compute_rmsd, apply_transformation_protein, batch_search_totals, set_batch_speculation, set_batch_icp_one_launch)
 from . import driver  # noqa: F401
 from . import synth  # noqa: F401
 from . import c4_batch  # noqa: F401

@@ -244,6 +244,11 @@ class GoICP:
         if dt_mode:
             self.set_dt_mode(dt_mode)
 
+    def set_icp_one_launch(self, on):
+        """ICP3D::Run of cavity-sized clouds as one launch per call (include/goicp_c.h: goicp_set_icp_one_launch); off by default."""
+        if self.L.goicp_set_icp_one_launch(self.h, int(bool(on))) != GOICP_OK:
+            raise EngineError("set_icp_one_launch")
+
     def set_dt_mode(self, mode):
         """0: the reference's DT3D::Build restated on the host (bit-identical grid); 1: exact transform built on the device (opt-in)."""
         if self.L.goicp_set_dt_mode(self.h, int(mode)) != GOICP_OK:
@@ -391,6 +396,11 @@ def batch_search_totals(reset=False):
     load_library().goicp_batch_search_totals(out.ctypes.data_as(C.c_void_p), int(bool(reset)))
     keys = ("registrations", "pops_launched", "pops_consumed", "jobs_launched", "inner_calls_consumed", "launches")
     return {k: int(v) for k, v in zip(keys, out)}
+
+
+def set_batch_icp_one_launch(on):
+    """ICP mode of run_pair_files for the whole process (include/goicp_c.h: goicp_set_batch_icp_one_launch); -1 = class default (off)."""
+    load_library().goicp_set_batch_icp_one_launch(int(on))
 
 
 def run_pair_files(base_dir, target_mol2, source_mol2, nd, config, output, pair, device_id=0, verbose=0):

@@ -123,7 +123,12 @@ public:
     int parity_mode = 1;          // see goicp_engine_desc::parity_mode
     int dt_mode = 0;              // 0: DT3D::Build restated on the host (bit-identical to the reference grid); 1: exact Euclidean transform built on the device (opt-in, see csrc/dt_gpu.hip)
     int speculate = 128;           // 0: one InnerBnB per launch; 1: the <=16 calls of a rotation pop per launch; M>1: also those of the next M-1 queue nodes
-    bool device_icp = true;       // untrimmed cavity-sized clouds: ICP3D::Run as one launch (goicp_engine_icp_loop); false: one launch per iteration
+    // ICP3D::Run of cavity-sized clouds (<= 1024 data / 2048 model points) as ONE launch per call (k_icp_loop, one workgroup) instead of one search
+    // launch per iteration with the sums on the host. Same bits either way. One CU against the whole chip plus a host core: a registration that has
+    // the GPU to itself is slower with it (shipped pair 1: 5.2 vs 4.3 ms; 1024 points: 11.6 vs 2.1 ms), registrations that share the GPU are faster
+    // (configs[3] batch, 14 in flight: 634 vs 519 pairs/s) -- so it is off here and the batch driver switches it on (goicp_set_batch_icp_one_launch).
+    bool device_icp = false;
+    int icp_loop_max = 1024;      // data points up to which ICP3D::Run goes out as one launch (GOICP_ICP_LOOP_MAX)
     uint32_t spec_pop_budget = 20000;   // queue-pop budget of a speculative job (re-run unbounded if it turns out to be needed)
     // budgets for searches that cannot be run to convergence (BASELINE configs[4]: 50 000 points, MSEThresh 1e-5): Register() then returns the best
     // pose found so far with budget_hit = true and status OK. 0 = none (the reference's behaviour).

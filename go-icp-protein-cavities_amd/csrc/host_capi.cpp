@@ -101,6 +101,7 @@ int goicp_dt_geom(goicp_handle* h, double* g) {
     g[0] = d.xMin; g[1] = d.xMax; g[2] = d.yMin; g[3] = d.yMax; g[4] = d.zMin; g[5] = d.zMax; g[6] = d.scale; g[7] = d.SIZE;
     return GOICP_OK;
 }
+int goicp_set_icp_one_launch(goicp_handle* h, int on) { if (!h) return GOICP_ERR_ARG; h->g.device_icp = on != 0; return GOICP_OK; }
 int goicp_set_dt_mode(goicp_handle* h, int mode) { if (!h || (mode != 0 && mode != 1)) return GOICP_ERR_ARG; h->g.dt_mode = mode; return GOICP_OK; }
 
 int goicp_dt_dump(goicp_handle* h, float* dist, int32_t* nearest, int32_t* cell_color) {
@@ -240,6 +241,8 @@ static int finish(GoICP& g, double* res, double t_reg, double t_dt, const double
 
 static std::atomic<int> g_batch_speculate{-1};
 void goicp_set_batch_speculation(int depth) { g_batch_speculate.store(depth); }
+static std::atomic<int> g_batch_icp_loop{-1};
+void goicp_set_batch_icp_one_launch(int on) { g_batch_icp_loop.store(on); }
 
 // what the file pipeline's registrations of this process launched and what their replays consumed (speculation cost of a batch)
 static std::atomic<uint64_t> g_tot[6];
@@ -257,6 +260,7 @@ int goicp_run_pair_files(const char* base_dir, const char* target_mol2, const ch
     const std::string base = (base_dir && base_dir[0]) ? std::string(base_dir) + "/" : std::string();
     GoICP g;
     g.device_id = device_id; g.verbose = verbose;
+    { const int v = g_batch_icp_loop.load(); if (v >= 0) g.device_icp = v != 0; }
     { const int d = g_batch_speculate.load(); if (d >= 0) g.speculate = d; }                              // what the batch driver chose for its number of registrations in flight
     { const char* e = getenv("GOICP_SPECULATE"); if (e) g.speculate = std::max(0, atoi(e)); }           // experiment knobs of the batch path
     { const char* e = getenv("GOICP_SPEC_POPS"); if (e && atoi(e) > 0) g.spec_pop_budget = (uint32_t)atoi(e); }

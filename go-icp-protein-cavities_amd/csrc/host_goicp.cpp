@@ -284,6 +284,7 @@ void GoICP::neighborsWeights() {
 void GoICP::Initialize() {
     Clear();
     { const char* e = getenv("GOICP_DEVICE_ICP"); if (e) device_icp = atoi(e) != 0; }      // A/B knob, read once per registration
+    { const char* e = getenv("GOICP_ICP_LOOP_MAX"); if (e) icp_loop_max = atoi(e); }
     status = GOICP_OK; error_message.clear();
     normData_.resize(Nd);
     for (int i = 0; i < Nd; i++) normData_[i] = std::sqrt(pData[i].x * pData[i].x + pData[i].y * pData[i].y + pData[i].z * pData[i].z);
@@ -436,7 +437,7 @@ float GoICP::icp_run(Matrix& R, Matrix& t) {
         }
         if (i < n) std::sort(ka.begin(), ka.end());
     };
-    if (device_icp) {
+    if (device_icp && n <= icp_loop_max) {
         // cavity-sized clouds: the whole loop in one launch (k_icp_loop: same sums in the same order -- for trimmed runs the order of the sort by
         // distance --, same 3x3 algebra). It hands back early only at an iteration with an exact distance tie between model points, which the
         // kd-tree order below decides.

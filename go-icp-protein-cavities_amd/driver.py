@@ -186,6 +186,8 @@ def gpu_register_fn(base_dir, device_id=0):
     def configure_batch(threads):
         # registrations that share a GPU speculate less (measured at 14 in flight: 128 nodes ahead 549 pairs/s, 16 nodes 608, 4 nodes 518)
         binding.set_batch_speculation(batch_speculation(threads))
+        # ICP3D::Run as one launch per call (one workgroup) pays when the GPU is shared: 14 in flight 634 vs 519 pairs/s; alone 5.2 vs 4.3 ms per pair
+        binding.set_batch_icp_one_launch(1 if int(threads) >= 3 else 0)
     reg.configure_batch = configure_batch
     return reg
 

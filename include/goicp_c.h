@@ -36,6 +36,9 @@ int goicp_build_dt(goicp_handle*);                              /* GoICP::BuildD
  * 1: exact Euclidean transform built and kept on the device (goicp_dtgpu_build, include/goicp_engine.h) -- opt-in, differs from the
  *    reference's propagated approximation in a few cells */
 int goicp_set_dt_mode(goicp_handle*, int mode);
+/* ICP3D::Run (reference jly_icp3d.hpp:197-311) of clouds up to 1024 data / 2048 model points as ONE launch per call (goicp_engine_icp_loop[_trimmed]) instead
+ * of one correspondence launch per iteration with the sums on the host. Same bits. Off by default: faster only when several registrations share the GPU. */
+int goicp_set_icp_one_launch(goicp_handle*, int on);
 /* adopt externally built tables instead (geom4 = xMin,yMin,zMin,scale; nearest = linear cell index) */
 int goicp_load_dt(goicp_handle*, int S, const double* geom4, const float* dist, const int32_t* nearest,
                   const int32_t* cell_color, const int32_t* cell_ptr, const int32_t* cell_idx);
@@ -89,6 +92,9 @@ int goicp_run_pair_files(const char* base_dir, const char* target_mol2, const ch
  * shares the GPU between them and does better with less: at T = 14 the configs[3] batch runs at 549 pairs/s with 128, 608 with 16,
  * 518 with 4. The environment variable GOICP_SPECULATE overrides it. */
 void goicp_set_batch_speculation(int depth);
+/* The same switch for goicp_run_pair_files (process-wide; -1 = the class default, off): a batch that keeps several registrations in flight turns it on
+ * (configs[3] batch, 14 in flight: 634 pairs/s with it, 519 without; one registration alone: 4.3 ms without it, 5.2 ms with). GOICP_DEVICE_ICP overrides. */
+void goicp_set_batch_icp_one_launch(int on);
 /* Totals over the goicp_run_pair_files calls of this process since the last reset (any host thread): out6 = registrations, translation-queue
  * pops LAUNCHED (of every search job sent to the device, consumed by the replay or not), pops CONSUMED (the reference's own pop count,
  * jly_goicp.cpp:297-333), search jobs launched, InnerBnB calls consumed (jly_goicp.cpp:706,810), launches. launched / consumed is what the

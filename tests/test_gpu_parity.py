@@ -175,13 +175,16 @@ def test_icp_nn_on_the_sorted_model_equals_the_exhaustive_search(monkeypatch):
     e.close(); e0.close()
 
 
+@pytest.mark.parametrize("one_launch", [False, True], ids=["launch_per_iteration", "one_launch"])
 @pytest.mark.parametrize("name", ["pair1_default", "pair1_trim", "pair1_fpfh"])
-def test_icp_against_reference_fixtures(name):
+def test_icp_against_reference_fixtures(name, one_launch):
     """GoICP::ICP through the C ABI (goicp_icp) on the compiled reference's in/out records (tests/golden/icp_*.npz): error,
-    correspondences and distances bit for bit, R, t to 1e-12 (own Jacobi SVD vs the reference's Golub-Kahan routine)."""
+    correspondences and distances bit for bit, R, t to 1e-12 (own Jacobi SVD vs the reference's Golub-Kahan routine) -- with one
+    correspondence launch per iteration (the default of a lone registration) and with the whole loop in one launch (what a batch switches on)."""
     I = dict(np.load(os.path.join(GOLDEN, "icp_%s.npz" % name)))
     P = load_clouds("pair1")
-    g = goicp_amd.GoICP(I["cfg"]); g.set_clouds(P["t"], P["s"], P["tc"], P["sc"], P["tf"], P["sf"]); g.build_dt(); g.initialize()
+    g = goicp_amd.GoICP(I["cfg"]); g.set_icp_one_launch(one_launch)
+    g.set_clouds(P["t"], P["s"], P["tc"], P["sc"], P["tf"], P["sf"]); g.build_dt(); g.initialize()
     for k in range(len(I["err"])):
         e, R, t, corr, dis = g.icp(I["Rin"][k], I["tin"][k])
         assert e == I["err"][k]
@@ -224,12 +227,14 @@ def test_trimmed_icp_in_one_launch_equals_the_host_loop(monkeypatch, nd, nm, tri
         assert np.array_equal(a[3], b[3]) and np.array_equal(a[4], b[4])
 
 
+@pytest.mark.parametrize("one_launch", [False, True], ids=["launch_per_iteration", "one_launch"])
 @pytest.mark.parametrize("name", ["plain", "trim", "geo"])
-def test_icp_tie_rule_against_reference_fixture(name):
+def test_icp_tie_rule_against_reference_fixture(name, one_launch):
     """Exact distance ties (duplicated model points, lattice-midpoint queries): the device search reports them and the host
     names the point the reference's kd-tree visits first (nanoflann.hpp:1137-1184); known answers from the compiled reference."""
     I = dict(np.load(os.path.join(GOLDEN, "icp_ties.npz")))
-    g = goicp_amd.GoICP(I[name + "_cfg"]); g.set_clouds(I[name + "_model"], I[name + "_data"]); g.build_dt(); g.initialize()
+    g = goicp_amd.GoICP(I[name + "_cfg"]); g.set_icp_one_launch(one_launch)
+    g.set_clouds(I[name + "_model"], I[name + "_data"]); g.build_dt(); g.initialize()
     ids, d, nt = g.engine().icp_nn(np.eye(3), np.zeros(3), ties=True)
     assert (nt > 1).sum() >= 100                                   # the case really is tie-heavy
     for k in range(len(I[name + "_err"])):
@@ -244,11 +249,12 @@ REG = ["pair1_default", "pair1_fpfh", "pair1_fpfh33", "pair1_color8", "pair1_nor
        "pair1_S300"]         # pair1_S300 = BASELINE configs[1]: the shipped cavity pair on a 300^3 DT
 
 
+@pytest.mark.parametrize("one_launch", [False, True], ids=["icp_launch_per_iteration", "icp_one_launch"])
 @pytest.mark.parametrize("name", REG)
-def test_register_against_reference_known_answers(name):
+def test_register_against_reference_known_answers(name, one_launch):
     """Whole GoICP::Register() on the GPU path vs the compiled reference's R, t, error, compat and Error* trace."""
     G = load_register()[name]; P = load_clouds("pair1")
-    g = goicp_amd.GoICP(cfg_vector(**G["cfg"])[0])
+    g = goicp_amd.GoICP(cfg_vector(**G["cfg"])[0]); g.set_icp_one_launch(one_launch)
     g.set_clouds(P["t"], P["s"], P["tc"], P["sc"], P["tf"], P["sf"])
     g.build_dt()
     out = g.register()

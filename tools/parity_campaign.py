@@ -30,7 +30,8 @@ def one(k):
     P = synth_pair(n, seed=31000 + k, noise=0.01, outlier_frac=float(rng.choice([0.0, 0.05, 0.15])), theta_range=(0.3, np.pi), corr_features=True)
     v, _ = cfg_vector(**over)
     t0 = time.time()
-    g = goicp_amd.GoICP(goicp_amd.cfg_vector(**over)); g.set_clouds(P["t"], P["s"], P["tc"], P["sc"], P["tf"], P["sf"]); g.build_dt()
+    g = goicp_amd.GoICP(goicp_amd.cfg_vector(**over)); g.set_icp_one_launch(k & 1)      # odd pairs: ICP3D::Run as one launch (what a batch switches on)
+    g.set_clouds(P["t"], P["s"], P["tc"], P["sc"], P["tf"], P["sf"]); g.build_dt()
     rg = g.register(); g.close(); t_gpu = time.time() - t0
     if rg["stats"]["cube_evals"] > 300000:            # the single-threaded oracle would need minutes: not compared
         return k, name, n, None, float("nan"), float(rg["error"]), 0.0, t_gpu, rg["stats"]["cube_evals"]
