@@ -8,7 +8,7 @@ import goicp_amd
 from helpers import load_clouds
 for name in ("pair1", "pair2"):
     P = load_clouds(name)
-    g = goicp_amd.GoICP(goicp_amd.cfg_vector()); g.set_clouds(P["t"], P["s"], P["tc"], P["sc"], P["tf"], P["sf"]); g.build_dt(); g.initialize()
+    g = goicp_amd.GoICP(goicp_amd.cfg_vector()); g.set_icp_one_launch(True); g.set_clouds(P["t"], P["s"], P["tc"], P["sc"], P["tf"], P["sf"]); g.build_dt(); g.initialize()
     e = g.engine()
     rng = np.random.default_rng(3)
     for k in range(6):
