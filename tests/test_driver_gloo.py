@@ -240,3 +240,25 @@ def test_worker_threads_leave_two_cpus_of_the_budget_free():
     assert driver.host_cpu_budget() >= 1
     assert driver.worker_threads(16, 1, 16) == 14 and driver.worker_threads(16, 8, 128) == 14
     assert driver.worker_threads(4, 1, 16) == 4 and driver.worker_threads(16, 1, 2) == 1 and driver.worker_threads(16, 2, 16) == 6
+
+
+def test_batch_driver_tells_the_library_how_many_registrations_are_in_flight(small_batch, tmp_path, monkeypatch):
+    """run_batch hands its thread count to the registration function's configure_batch; the GPU one (driver.gpu_register_fn) turns it into the
+    two process-wide settings of the file pipeline: the speculation depth (128 alone ... 16 from 16 in flight on) and ICP3D::Run in one launch
+    from three registrations in flight on (include/goicp_c.h: goicp_set_batch_speculation, goicp_set_batch_icp_one_launch)."""
+    d, tsv, cfgp, _ = small_batch
+    seen = []
+
+    def reg(tf, sf, nd, config, output, k):
+        return _fake_register(tf, sf, nd, config, output, k)
+    reg.configure_batch = seen.append
+    recs, n = driver.run_batch(d, tsv, cfgp, str(tmp_path / "o"), reg, threads=5, rmsd=False)
+    assert seen == [5] and len(recs) == 14
+    assert [driver.batch_speculation(t) for t in (1, 2, 3, 8, 14, 16, 64)] == [128, 128, 85, 32, 18, 16, 16]
+    calls = []
+    from goicp_amd import binding
+    monkeypatch.setattr(binding, "set_batch_speculation", lambda depth: calls.append(("spec", depth)))
+    monkeypatch.setattr(binding, "set_batch_icp_one_launch", lambda on: calls.append(("icp", on)))
+    for t in (1, 2, 3, 14):
+        driver.gpu_register_fn(d).configure_batch(t)
+    assert calls == [("spec", 128), ("icp", 0), ("spec", 128), ("icp", 0), ("spec", 85), ("icp", 1), ("spec", 18), ("icp", 1)]
