@@ -117,9 +117,12 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         # RCCL on ROCm. Rehearsal of the N > 1 path on a ONE-GPU box (never the measured configuration): GOICP_BENCH_BACKEND=gloo with
         # GOICP_BENCH_ONE_GPU=1 puts every rank on device 0 (RCCL refuses two ranks on one device); the JSON line then says so in `rehearsal`.
-        dist.init_process_group(os.environ.get("GOICP_BENCH_BACKEND", "nccl"))
-    if os.environ.get("GOICP_BENCH_ONE_GPU") == "1":
-        local = 0
+        if os.environ.get("GOICP_BENCH_ONE_GPU") == "1":
+            local = 0
+        torch.cuda.set_device(local)
+        backend = os.environ.get("GOICP_BENCH_BACKEND", "nccl")
+        # device_id: the rank's communicator is bound to ITS GPU at once (no guessing the device from the global rank at the first barrier)
+        dist.init_process_group(backend, **({"device_id": torch.device("cuda", local)} if backend == "nccl" else {}))
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
 
